@@ -1,0 +1,143 @@
+/*
+ * vokselis_hip.h -- C-ABI of the MI355X-native vokselis raycast path.
+ *
+ * The reference (pudnax/vokselis) has no FFI: its hot path sits behind the wgpu bind-group
+ * contract of shaders/raycast_naive.wgsl and shaders/raycast_compute.wgsl, driven from
+ * `Demo::render(&mut self, &Context)` (src/lib.rs:42,178-181).  Each entry point below replaces
+ * one wgpu-side step of that contract; the reference lines it replaces are cited per function.
+ * INTEGRATION.md shows the `extern "C"` block a Rust maintainer would add to bind it.
+ *
+ * Conventions: 0 = VK_OK, negative = error, nothing aborts or throws across the boundary.
+ * The caller owns every host pointer; the library owns all device memory it allocates.  A
+ * vk_ctx is bound to one GPU and one HIP stream and is not thread-safe (the reference drives
+ * its queue from the single winit thread, src/lib.rs:71).
+ */
+#ifndef VOKSELIS_HIP_H
+#define VOKSELIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+typedef struct vk_ctx vk_ctx;
+
+enum vk_status {
+    VK_OK = 0,
+    VK_ERR_INVALID = -1,   /* bad argument / wrong state */
+    VK_ERR_HIP = -2,       /* a HIP runtime call failed; see vk_last_error */
+    VK_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    VK_ERR_OOM = -4,
+    VK_ERR_UNSUPPORTED = -5
+};
+
+/* src/context/volume_texture.rs:39-47 (R8Unorm), SURVEY C4 (R16Float),
+ * examples/xor/xor_compute.rs:94-118 (two rgba16float storage textures). */
+enum vk_volume_format { VK_FMT_R8_UNORM = 0, VK_FMT_R16_FLOAT = 1, VK_FMT_RGBA16F_PAIR = 2 };
+
+/* raycast_naive.wgsl fs_main vs raycast_compute.wgsl render()/get_col2 */
+enum vk_mode { VK_MODE_NAIVE_TRILINEAR = 0, VK_MODE_COMPUTE_NEAREST = 1 };
+
+/* src/context/hdr_backbuffer.rs:10 is rgba16float; RGBA32F is the parity surface. */
+enum vk_out_format { VK_OUT_RGBA32F = 0, VK_OUT_RGBA16F = 1 };
+
+/* How the library lays the scalar volume out in HBM (DESIGN.md "Data layout"). */
+enum vk_layout {
+    VK_LAYOUT_AUTO = 0,
+    VK_LAYOUT_LINEAR = 1, /* x-fastest as uploaded; 8 scalar taps per sample (validation kernel) */
+    VK_LAYOUT_PACKED = 2  /* 4^3-bricked cells, each holding its 8 trilinear taps (+ skip map) */
+};
+
+enum vk_render_flags {
+    VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
+    VK_RENDER_COUNT = 2     /* also accumulate step counters / per-pixel step counts */
+};
+
+/* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */
+int vk_ctx_create(int device_ordinal, vk_ctx **out);
+int vk_ctx_destroy(vk_ctx *ctx);
+/* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own. */
+int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream);
+int vk_ctx_sync(vk_ctx *ctx);
+/* Context::get_info, src/context.rs:183-203 */
+int vk_device_info(vk_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *arch_is_gfx950,
+                   size_t *total_mem_bytes);
+/* Message for the last failing call on this context (ctx == NULL: last vk_ctx_create failure). */
+const char *vk_last_error(vk_ctx *ctx);
+int vk_abi_version(void);
+
+/* ---- inputs ------------------------------------------------------------------------------ */
+/* VolumeTexture::new: create_texture + queue.write_texture, src/context/volume_texture.rs:32-59.
+ * `host` is the dense x-fastest array (index x + nx*(y + ny*z)); `host2` only for RGBA16F_PAIR
+ * (normals).  The library re-lays it out on the device (layout) and builds the skip map. */
+int vk_volume_upload(vk_ctx *ctx, const void *host, const void *host2, uint32_t nx, uint32_t ny, uint32_t nz,
+                     int format, int layout);
+/* Same, but the dense source already lives in device memory of this GPU (large synthetic volumes). */
+int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint32_t nx, uint32_t ny,
+                            uint32_t nz, int format, int layout);
+/* Deterministic fog volume generated on the device (bit-identical to oracle vo_volume_fog_*):
+ * kind 0 = u8 in [lo, lo+span), kind 1 = f16 bit patterns 0x2D1F + h % 656. */
+int vk_volume_generate_fog(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
+                           uint32_t lo, uint32_t span, int layout);
+int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes);
+
+/* GlobalUniformBinding::update, src/context/global_ubo.rs:47-49 (48-byte Uniform, :52-65). */
+int vk_set_uniform(vk_ctx *ctx, const void *blob48);
+/* CameraBinding::update, src/camera.rs:62-71 (144-byte CameraUniform, :5-11).  Always uploads
+ * (the reference's `updated` gate leaves the first frame with an identity camera). */
+int vk_set_camera(vk_ctx *ctx, const void *blob144);
+
+/* ---- output surface: HdrBackBuffer::new, src/context/hdr_backbuffer.rs:41-87 ------------- */
+int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_format);
+int vk_backbuffer_info(vk_ctx *ctx, uint32_t *width, uint32_t *height, int *out_format, void **device_ptr);
+/* Clear to the render pass's LoadOp::Clear(BLACK) = (0,0,0,1), examples/bonsai/main.rs:41. */
+int vk_backbuffer_clear(vk_ctx *ctx);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* One raycast pass over a tile of the backbuffer, asynchronous on the context's stream.
+ * NAIVE: RaycastPipeline::record + queue.submit (examples/bonsai/raycast.rs:118-135,
+ * examples/bonsai/main.rs:27-57).  COMPUTE: the `single`/`tile` dispatches with their pixel
+ * offset (examples/xor/main.rs:223-254, raycast_compute.wgsl:133-144); pixels of the tile that
+ * fall outside the backbuffer are dropped like out-of-range textureStores. */
+int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t tile_w, uint32_t tile_h,
+              float dt_scale, uint32_t flags);
+
+/* Multi-GPU partition of one frame: the backbuffer-sized frame is cut into tile_size^2 tiles
+ * (row-major; the reference's TILE_SIZE scheme, examples/xor/main.rs:12,77-95); this call
+ * renders the tiles t with t % nranks == rank into `compact_out` (device memory,
+ * [n_slots][tile_size][tile_size] pixels of the backbuffer's format, slot j <-> tile rank+j*nranks).
+ * vk_partition_slots gives n_slots (identical on every rank, for a fixed-size gather). */
+int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots);
+int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                        float dt_scale, uint32_t flags, void *compact_out);
+/* Root side: scatter the gathered [nranks][n_slots][ts][ts] pixels into the backbuffer. */
+int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks);
+
+/* ---- results ----------------------------------------------------------------------------- */
+/* ScreenshotCtx::capture_frame's copy_texture_to_buffer + map, src/context/screenshot.rs:37-77.
+ * Blocking.  row_pitch_bytes >= width * bytes_per_pixel. */
+int vk_readback(vk_ctx *ctx, void *dst, size_t row_pitch_bytes);
+/* Counters of the launches since the last reset (flag VK_RENDER_COUNT): loop iterations the
+ * reference would execute (S_ref) and iterations in which taps were fetched (S_sampled). */
+int vk_step_counts(vk_ctx *ctx, uint64_t *s_ref, uint64_t *s_sampled);
+int vk_step_counts_reset(vk_ctx *ctx);
+/* Per-pixel executed loop iterations of the last VK_RENDER_COUNT launch ([height][width] u32). */
+int vk_readback_steps(vk_ctx *ctx, uint32_t *dst);
+
+/* hipEvent bracket on the context's stream -- the analogue of the reference's timestamp
+ * queries around the raycast pass (examples/xor/main.rs:217,258-259,164-187). */
+int vk_timer_begin(vk_ctx *ctx);
+int vk_timer_end(vk_ctx *ctx);
+int vk_timer_elapsed_ms(vk_ctx *ctx, float *ms); /* blocks until the end event has passed */
+
+/* dispatch_optimal, src/utils/mod.rs:15-18 */
+uint32_t vk_dispatch_optimal(uint32_t len, uint32_t subgroup_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOKSELIS_HIP_H */

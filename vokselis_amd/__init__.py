@@ -1,0 +1,24 @@
+"""vokselis_amd -- MI355X-native (gfx950) volume raymarcher behind the surface of pudnax/vokselis.
+
+Only the raycast hot path and the host surface that drives it live here:
+  csrc/      hand-written HIP kernels + the C-ABI (include/vokselis_hip.h)
+  _native    ctypes binding of that C-ABI (fails loudly when the .so is missing)
+  camera     Camera / CameraUniform            (src/camera.rs)
+  context    Context, Uniform, HdrBackBuffer, VolumeTexture, RaycastPipeline, Demo, run_headless
+  volumes    deterministic synthetic volumes (bonsai stand-in, fog)
+  dist       tile-parallel multi-GPU frame (one process per GPU, RCCL gather over xGMI)
+"""
+from . import _native as native
+from ._native import (FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR, LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED,
+                      MODE_COMPUTE_NEAREST, MODE_NAIVE_TRILINEAR, OUT_RGBA16F, OUT_RGBA32F, RENDER_COUNT,
+                      RENDER_NO_SKIP, VokselisError)
+from .camera import Camera
+from .context import (Context, Demo, FrameCounter, HdrBackBuffer, ImageDimentions, RaycastPipeline, Uniform,
+                      VolumeTexture, dispatch_optimal, partition_slots, run_headless)
+
+__all__ = [
+    "native", "Camera", "Context", "Demo", "FrameCounter", "HdrBackBuffer", "ImageDimentions", "RaycastPipeline",
+    "Uniform", "VolumeTexture", "dispatch_optimal", "partition_slots", "run_headless", "VokselisError",
+    "FMT_R8_UNORM", "FMT_R16_FLOAT", "FMT_RGBA16F_PAIR", "LAYOUT_AUTO", "LAYOUT_LINEAR", "LAYOUT_PACKED",
+    "MODE_COMPUTE_NEAREST", "MODE_NAIVE_TRILINEAR", "OUT_RGBA16F", "OUT_RGBA32F", "RENDER_COUNT", "RENDER_NO_SKIP",
+]

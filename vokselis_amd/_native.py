@@ -1,0 +1,84 @@
+"""ctypes binding of the C-ABI in include/vokselis_hip.h (libvokselis_hip.so).
+
+There is no CPU fallback: if the shared library is missing, or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libvokselis_hip.so")
+
+VK_OK = 0
+FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
+MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
+OUT_RGBA32F, OUT_RGBA16F = 0, 1
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED = 0, 1, 2
+RENDER_NO_SKIP, RENDER_COUNT = 1, 2
+
+# every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
+_u32, _i32, _f32, _vp, _sz = C.c_uint32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+SYMBOLS = {
+    "vk_abi_version": (C.c_int, []),
+    "vk_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "vk_ctx_destroy": (C.c_int, [_vp]),
+    "vk_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "vk_ctx_sync": (C.c_int, [_vp]),
+    "vk_device_info": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "vk_last_error": (C.c_char_p, [_vp]),
+    "vk_volume_upload": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
+    "vk_volume_upload_device": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
+    "vk_volume_generate_fog": (C.c_int, [_vp, _u32, _u32, _u32, C.c_int, _u32, _u32, _u32, C.c_int]),
+    "vk_volume_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "vk_set_uniform": (C.c_int, [_vp, _vp]),
+    "vk_set_camera": (C.c_int, [_vp, _vp]),
+    "vk_backbuffer_resize": (C.c_int, [_vp, _u32, _u32, C.c_int]),
+    "vk_backbuffer_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "vk_backbuffer_clear": (C.c_int, [_vp]),
+    "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
+    "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "vk_render_partition": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),
+    "vk_untile": (C.c_int, [_vp, _vp, _u32, _u32]),
+    "vk_readback": (C.c_int, [_vp, _vp, _sz]),
+    "vk_step_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vk_step_counts_reset": (C.c_int, [_vp]),
+    "vk_readback_steps": (C.c_int, [_vp, _vp]),
+    "vk_timer_begin": (C.c_int, [_vp]),
+    "vk_timer_end": (C.c_int, [_vp]),
+    "vk_timer_elapsed_ms": (C.c_int, [_vp, C.POINTER(_f32)]),
+    "vk_dispatch_optimal": (_u32, [_u32, _u32]),
+}
+
+
+class VokselisError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vokselis_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libvokselis_hip.so; raise (never fall back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(ctx, rc: int):
+    if rc != VK_OK:
+        msg = lib().vk_last_error(ctx)
+        raise VokselisError(rc, msg.decode() if msg else "")

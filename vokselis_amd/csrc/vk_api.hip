@@ -1,0 +1,565 @@
+// vk_api.hip -- C-ABI (include/vokselis_hip.h) over the kernels in vk_kernels.hpp.
+// gfx950 only; no CPU fallback: every entry point fails with VK_ERR_HIP / VK_ERR_NO_DEVICE
+// when the HIP runtime or the device is unavailable.
+#include "../../include/vokselis_hip.h"
+#include "vk_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace vk;
+
+struct vk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop{};
+
+    // volume
+    void *vol = nullptr, *vol2 = nullptr;  // cells / dense voxels / pair
+    uint8_t *dist = nullptr;
+    size_t vol_bytes = 0;
+    uint32_t nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
+    int format = -1, layout = 0;
+
+    // uniforms (host copies; passed to kernels by value)
+    unsigned char uniform[48] = {0};
+    float camera[36] = {0};  // 144-byte CameraUniform
+    bool have_camera = false;
+
+    // output
+    void *backbuffer = nullptr;
+    uint32_t width = 0, height = 0;
+    int out_format = VK_OUT_RGBA32F;
+    uint32_t *steps = nullptr;
+    unsigned long long *counters = nullptr;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_open = false, timing_done = false;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(vk_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? VK_ERR_OOM : VK_ERR_HIP,              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+        }                                                                                      \
+    } while (0)
+
+static size_t px_bytes(int fmt) { return fmt == VK_OUT_RGBA16F ? 8 : 16; }
+
+extern "C" {
+
+int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+uint32_t vk_dispatch_optimal(uint32_t len, uint32_t subgroup_size) {
+    if (subgroup_size == 0) return 0;
+    uint32_t padded = (subgroup_size - len % subgroup_size) % subgroup_size;
+    return (len + padded) / subgroup_size;
+}
+
+const char *vk_last_error(vk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int vk_ctx_create(int device_ordinal, vk_ctx **out) {
+    if (!out) return fail(nullptr, VK_ERR_INVALID, "vk_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, VK_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, VK_ERR_INVALID, "vk_ctx_create: device ordinal out of range");
+    vk_ctx *ctx = new (std::nothrow) vk_ctx();
+    if (!ctx) return fail(nullptr, VK_ERR_OOM, "vk_ctx_create: host allocation failed");
+    ctx->device = device_ordinal;
+    auto bail = [&](hipError_t err, const char *what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return fail(nullptr, VK_ERR_HIP, msg);
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string msg = std::string("device is ") + ctx->prop.gcnArchName + ", this library carries gfx950 code only";
+        delete ctx;
+        return fail(nullptr, VK_ERR_NO_DEVICE, msg);
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&ctx->counters, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemset(ctx->counters, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(counters)");
+    *out = ctx;
+    return VK_OK;
+}
+
+static void free_volume(vk_ctx *ctx) {
+    if (ctx->vol) (void)hipFree(ctx->vol);
+    if (ctx->vol2) (void)hipFree(ctx->vol2);
+    if (ctx->dist) (void)hipFree(ctx->dist);
+    ctx->vol = ctx->vol2 = nullptr;
+    ctx->dist = nullptr;
+    ctx->vol_bytes = 0;
+    ctx->format = -1;
+}
+
+int vk_ctx_destroy(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_volume(ctx);
+    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
+    if (ctx->steps) (void)hipFree(ctx->steps);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VK_OK;
+}
+
+int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VK_OK;
+}
+
+int vk_ctx_sync(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_device_info(vk_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *arch_is_gfx950,
+                   size_t *total_mem_bytes) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (name && name_cap) std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (arch_is_gfx950) *arch_is_gfx950 = std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) == 0;
+    if (total_mem_bytes) *total_mem_bytes = ctx->prop.totalGlobalMem;
+    return VK_OK;
+}
+
+// ---- volume ------------------------------------------------------------------------------------
+
+static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, bool own_src, uint32_t nx,
+                            uint32_t ny, uint32_t nz, int format, int layout) {
+    // d_src is dense device memory; for LINEAR / PAIR with own_src the context adopts it.
+    const size_t n_vox = (size_t)nx * ny * nz;
+    const size_t bpv = format == VK_FMT_R8_UNORM ? 1 : (format == VK_FMT_R16_FLOAT ? 2 : 8);
+    if (layout == VK_LAYOUT_AUTO) layout = format == VK_FMT_RGBA16F_PAIR ? VK_LAYOUT_LINEAR : VK_LAYOUT_PACKED;
+    if (format == VK_FMT_RGBA16F_PAIR && layout != VK_LAYOUT_LINEAR)
+        return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR volumes use the linear layout (nearest-neighbour loads)");
+    free_volume(ctx);
+    ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
+    ctx->format = format;
+    ctx->layout = layout;
+    ctx->nbx = ctx->nby = ctx->nbz = 0;
+    if (layout == VK_LAYOUT_LINEAR) {
+        if (own_src) {
+            ctx->vol = const_cast<void *>(d_src);
+            ctx->vol2 = const_cast<void *>(d_src2);
+        } else {
+            HIP_TRY(ctx, hipMalloc(&ctx->vol, n_vox * bpv));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->vol, d_src, n_vox * bpv, hipMemcpyDeviceToDevice, ctx->stream));
+            if (d_src2) {
+                HIP_TRY(ctx, hipMalloc(&ctx->vol2, n_vox * bpv));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->vol2, d_src2, n_vox * bpv, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        ctx->vol_bytes = n_vox * bpv * (d_src2 ? 2 : 1);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return VK_OK;
+    }
+    // PACKED: (n+1) cells per axis, rounded up to whole 4^3 bricks
+    const bool f16 = format == VK_FMT_R16_FLOAT;
+    ctx->nbx = (nx + 1 + kBrick - 1) / kBrick;
+    ctx->nby = (ny + 1 + kBrick - 1) / kBrick;
+    ctx->nbz = (nz + 1 + kBrick - 1) / kBrick;
+    const uint64_t n_bricks = (uint64_t)ctx->nbx * ctx->nby * ctx->nbz;
+    const uint64_t n_cells = n_bricks * kBrickCells;
+    const size_t cell_bytes = f16 ? 16 : 8;
+    if (n_bricks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for 32-bit brick indices");
+    HIP_TRY(ctx, hipMalloc(&ctx->vol, n_cells * cell_bytes));
+    uint8_t *tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->dist, n_bricks));
+    HIP_TRY(ctx, hipMalloc(&tmp, n_bricks));
+    ctx->vol_bytes = n_cells * cell_bytes + n_bricks;
+    const uint32_t pack_blocks = (uint32_t)((n_cells + 255) / 256);
+    if (f16) {
+        hipLaunchKernelGGL(pack_cells_kernel<true>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
+        hipLaunchKernelGGL(brick_occupancy_kernel<true>, dim3((uint32_t)n_bricks), dim3(64), 0, ctx->stream, ctx->vol, ctx->dist, n_bricks);
+    } else {
+        hipLaunchKernelGGL(pack_cells_kernel<false>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
+        hipLaunchKernelGGL(brick_occupancy_kernel<false>, dim3((uint32_t)n_bricks), dim3(64), 0, ctx->stream, ctx->vol, ctx->dist, n_bricks);
+    }
+    const uint32_t db = (uint32_t)((n_bricks + 255) / 256);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 0, 0);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, tmp, ctx->dist, ctx->nbx, ctx->nby, ctx->nbz, 1, 0);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 2, 1);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { (void)hipFree(tmp); return fail(ctx, VK_ERR_HIP, std::string("volume re-layout launch: ") + hipGetErrorString(le)); }
+    hipError_t ce = hipMemcpyAsync(ctx->dist, tmp, n_bricks, hipMemcpyDeviceToDevice, ctx->stream);
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (own_src) { (void)hipFree(const_cast<void *>(d_src)); }
+    if (ce != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("dist copy: ") + hipGetErrorString(ce));
+    if (se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("volume re-layout: ") + hipGetErrorString(se));
+    return VK_OK;
+}
+
+static int check_volume_args(vk_ctx *ctx, const void *p, const void *p2, uint32_t nx, uint32_t ny, uint32_t nz, int format,
+                             int layout) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!p) return fail(ctx, VK_ERR_INVALID, "volume pointer is NULL");
+    if (nx == 0 || ny == 0 || nz == 0 || nx > 8192 || ny > 8192 || nz > 8192)
+        return fail(ctx, VK_ERR_INVALID, "volume dims must be in [1, 8192]");
+    if (format < VK_FMT_R8_UNORM || format > VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_INVALID, "unknown volume format");
+    if (format == VK_FMT_RGBA16F_PAIR && !p2) return fail(ctx, VK_ERR_INVALID, "RGBA16F_PAIR needs the normals volume");
+    if (layout < VK_LAYOUT_AUTO || layout > VK_LAYOUT_PACKED) return fail(ctx, VK_ERR_INVALID, "unknown layout");
+    return VK_OK;
+}
+
+int vk_volume_upload(vk_ctx *ctx, const void *host, const void *host2, uint32_t nx, uint32_t ny, uint32_t nz,
+                     int format, int layout) {
+    int rc = check_volume_args(ctx, host, host2, nx, ny, nz, format, layout);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_vox = (size_t)nx * ny * nz;
+    const size_t bpv = format == VK_FMT_R8_UNORM ? 1 : (format == VK_FMT_R16_FLOAT ? 2 : 8);
+    void *d = nullptr, *d2 = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, n_vox * bpv));
+    hipError_t e = hipMemcpy(d, host, n_vox * bpv, hipMemcpyHostToDevice);
+    if (e == hipSuccess && format == VK_FMT_RGBA16F_PAIR) {
+        e = hipMalloc(&d2, n_vox * bpv);
+        if (e == hipSuccess) e = hipMemcpy(d2, host2, n_vox * bpv, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        if (d2) (void)hipFree(d2);
+        return fail(ctx, VK_ERR_HIP, std::string("volume upload: ") + hipGetErrorString(e));
+    }
+    return build_from_dense(ctx, d, d2, true, nx, ny, nz, format, layout);
+}
+
+int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint32_t nx, uint32_t ny, uint32_t nz,
+                            int format, int layout) {
+    int rc = check_volume_args(ctx, dev, dev2, nx, ny, nz, format, layout);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return build_from_dense(ctx, dev, dev2, false, nx, ny, nz, format, layout);
+}
+
+int vk_volume_generate_fog(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed, uint32_t lo,
+                           uint32_t span, int layout) {
+    int dummy = 0;
+    int rc = check_volume_args(ctx, &dummy, nullptr, nx, ny, nz, format, layout);
+    if (rc) return rc;
+    if (format == VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_UNSUPPORTED, "fog generator makes scalar volumes");
+    if (format == VK_FMT_R8_UNORM && (span == 0 || lo + span > 256)) return fail(ctx, VK_ERR_INVALID, "fog range outside u8");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_vox = (size_t)nx * ny * nz;
+    const size_t bpv = format == VK_FMT_R8_UNORM ? 1 : 2;
+    void *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, n_vox * bpv));
+    const uint64_t blocks = (n_vox + 255) / 256;
+    if (blocks >= (1ull << 31)) { (void)hipFree(d); return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large"); }
+    if (format == VK_FMT_R16_FLOAT)
+        hipLaunchKernelGGL(fog_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+    else
+        hipLaunchKernelGGL(fog_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, VK_ERR_HIP, std::string("fog launch: ") + hipGetErrorString(e)); }
+    return build_from_dense(ctx, d, nullptr, true, nx, ny, nz, format, layout);
+}
+
+int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "no volume uploaded");
+    if (dims) { dims[0] = ctx->nx; dims[1] = ctx->ny; dims[2] = ctx->nz; }
+    if (format) *format = ctx->format;
+    if (layout) *layout = ctx->layout;
+    if (device_bytes) *device_bytes = ctx->vol_bytes;
+    return VK_OK;
+}
+
+// ---- uniforms ------------------------------------------------------------------------------------
+
+int vk_set_uniform(vk_ctx *ctx, const void *blob48) {
+    if (!ctx || !blob48) return fail(ctx, VK_ERR_INVALID, "vk_set_uniform: NULL argument");
+    std::memcpy(ctx->uniform, blob48, 48);  // read by neither fs_main nor get_col2
+    return VK_OK;
+}
+
+int vk_set_camera(vk_ctx *ctx, const void *blob144) {
+    if (!ctx || !blob144) return fail(ctx, VK_ERR_INVALID, "vk_set_camera: NULL argument");
+    std::memcpy(ctx->camera, blob144, 144);
+    for (int i = 0; i < 36; i++)
+        if (!std::isfinite(ctx->camera[i])) { ctx->have_camera = false; return fail(ctx, VK_ERR_INVALID, "camera blob has non-finite entries"); }
+    ctx->have_camera = true;
+    return VK_OK;
+}
+
+// ---- backbuffer ------------------------------------------------------------------------------------
+
+int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_format) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, VK_ERR_INVALID, "backbuffer size must be in [1, 32768]");
+    if (out_format != VK_OUT_RGBA32F && out_format != VK_OUT_RGBA16F) return fail(ctx, VK_ERR_INVALID, "unknown output format");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
+    if (ctx->steps) (void)hipFree(ctx->steps);
+    ctx->backbuffer = nullptr;
+    ctx->steps = nullptr;
+    ctx->width = ctx->height = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->backbuffer, (size_t)width * height * px_bytes(out_format)));
+    ctx->width = width;
+    ctx->height = height;
+    ctx->out_format = out_format;
+    return vk_backbuffer_clear(ctx);
+}
+
+int vk_backbuffer_info(vk_ctx *ctx, uint32_t *width, uint32_t *height, int *out_format, void **device_ptr) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (width) *width = ctx->width;
+    if (height) *height = ctx->height;
+    if (out_format) *out_format = ctx->out_format;
+    if (device_ptr) *device_ptr = ctx->backbuffer;
+    return VK_OK;
+}
+
+int vk_backbuffer_clear(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)ctx->width * ctx->height;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (ctx->out_format == VK_OUT_RGBA16F)
+        hipLaunchKernelGGL(clear_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->backbuffer, n);
+    else
+        hipLaunchKernelGGL(clear_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->backbuffer, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+// ---- render ------------------------------------------------------------------------------------
+
+}  // extern "C"
+
+template <int VOL, bool SKIP>
+static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
+    const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+    if (f16) {
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+    } else {
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+    }
+}
+
+static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                         uint32_t rank, uint32_t nranks, float dt_scale, uint32_t flags, void *compact_out) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "render: no volume uploaded");
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "render: no backbuffer (vk_backbuffer_resize)");
+    if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "render: no camera (vk_set_camera)");
+    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST) return fail(ctx, VK_ERR_INVALID, "unknown mode");
+    if (mode == VK_MODE_NAIVE_TRILINEAR && ctx->format == VK_FMT_RGBA16F_PAIR)
+        return fail(ctx, VK_ERR_INVALID, "NAIVE_TRILINEAR needs a scalar volume (R8_UNORM / R16_FLOAT)");
+    if (mode == VK_MODE_COMPUTE_NEAREST && ctx->format != VK_FMT_RGBA16F_PAIR)
+        return fail(ctx, VK_ERR_INVALID, "COMPUTE_NEAREST needs an RGBA16F_PAIR volume");
+    if (!(dt_scale > 0.0f) || !std::isfinite(dt_scale)) return fail(ctx, VK_ERR_INVALID, "dt_scale must be finite and > 0");
+    if (rw == 0 || rh == 0) return VK_OK;  // empty tile
+    if (ts == 0 || (ts & 7u) || ts > 1024) return fail(ctx, VK_ERR_INVALID, "tile size must be a multiple of 8 in [8, 1024]");
+    if (nranks == 0 || rank >= nranks) return fail(ctx, VK_ERR_INVALID, "rank/nranks");
+    // Loop-termination guard (the reference would hang the GPU on a dt that no longer advances t):
+    // t <= |eye - box| + box diagonal; require dt >= 8 ulp(t_max).
+    {
+        const float *e = ctx->camera;
+        float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
+        if (mode == VK_MODE_COMPUTE_NEAREST) reach += 200.0f;  // near-plane point of a far=100 frustum
+        float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
+        float dt_min = mode == VK_MODE_NAIVE_TRILINEAR ? dt_scale / nmax : dt_scale * 0.01f;
+        float ulp = std::nextafter(reach, 2.0f * reach) - reach;
+        if (!(dt_min >= 8.0f * ulp)) return fail(ctx, VK_ERR_UNSUPPORTED, "dt too small against the camera distance: the march would not advance");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool count = (flags & VK_RENDER_COUNT) != 0;
+    if (count && !ctx->steps) {
+        HIP_TRY(ctx, hipMalloc(&ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->steps, 0, (size_t)ctx->width * ctx->height * sizeof(uint32_t), ctx->stream));
+    }
+    LaunchDesc L{};
+    L.eye[0] = ctx->camera[0]; L.eye[1] = ctx->camera[1]; L.eye[2] = ctx->camera[2]; L.eye[3] = ctx->camera[3];
+    std::memcpy(L.inv_proj, ctx->camera + 20, 64);
+    L.W = ctx->width; L.H = ctx->height;
+    L.ox = ox; L.oy = oy; L.rw = rw; L.rh = rh;
+    L.ts = ts;
+    L.tiles_x = (rw + ts - 1) / ts;
+    L.tiles_y = (rh + ts - 1) / ts;
+    L.rank = rank; L.nranks = nranks;
+    const uint64_t tiles = (uint64_t)L.tiles_x * L.tiles_y;
+    const uint64_t slots = (tiles + nranks - 1) / nranks;
+    const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
+    const uint64_t n_blocks = slots * per_tile;
+    if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large");
+    L.n_blocks = (uint32_t)n_blocks;
+    L.compact = compact_out ? 1u : 0u;
+    L.dt_scale = dt_scale;
+    L.out = compact_out ? compact_out : ctx->backbuffer;
+    L.steps = count ? ctx->steps : nullptr;
+    L.counters = count ? ctx->counters : nullptr;
+    VolumeDesc V{};
+    V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
+    V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
+    V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
+    const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
+    if (mode == VK_MODE_COMPUTE_NEAREST) {
+        const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+        if (f16) {
+            if (count) hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+            else hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        } else {
+            if (count) hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+            else hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        }
+    } else {
+        const bool skip = !(flags & VK_RENDER_NO_SKIP);
+        const bool f16v = ctx->format == VK_FMT_R16_FLOAT;
+        if (ctx->layout == VK_LAYOUT_PACKED) {
+            if (f16v) { if (skip) launch_naive<VOL_PACKED_F16, true>(ctx, L, V, grid, count); else launch_naive<VOL_PACKED_F16, false>(ctx, L, V, grid, count); }
+            else { if (skip) launch_naive<VOL_PACKED_U8, true>(ctx, L, V, grid, count); else launch_naive<VOL_PACKED_U8, false>(ctx, L, V, grid, count); }
+        } else {
+            if (f16v) launch_naive<VOL_LINEAR_F16, false>(ctx, L, V, grid, count);
+            else launch_naive<VOL_LINEAR_U8, false>(ctx, L, V, grid, count);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+extern "C" {
+
+int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t tile_w, uint32_t tile_h, float dt_scale,
+              uint32_t flags) {
+    return render_common(ctx, mode, tile_x, tile_y, tile_w, tile_h, 64, 0, 1, dt_scale, flags, nullptr);
+}
+
+int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots) {
+    if (!n_slots || tile_size == 0 || (tile_size & 7u) || nranks == 0 || width == 0 || height == 0) return VK_ERR_INVALID;
+    uint64_t tiles = (uint64_t)((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
+    *n_slots = (uint32_t)((tiles + nranks - 1) / nranks);
+    return VK_OK;
+}
+
+int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks, float dt_scale,
+                        uint32_t flags, void *compact_out) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!compact_out) return fail(ctx, VK_ERR_INVALID, "vk_render_partition: compact_out is NULL");
+    return render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
+}
+
+int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks) {
+    if (!ctx || !gathered) return fail(ctx, VK_ERR_INVALID, "vk_untile: NULL argument");
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
+    uint32_t n_slots = 0;
+    if (vk_partition_slots(ctx->width, ctx->height, tile_size, nranks, &n_slots)) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)ctx->width * ctx->height;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
+    if (ctx->out_format == VK_OUT_RGBA16F)
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots);
+    else
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots);
+    HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+// ---- results ------------------------------------------------------------------------------------
+
+int vk_readback(vk_ctx *ctx, void *dst, size_t row_pitch_bytes) {
+    if (!ctx || !dst) return fail(ctx, VK_ERR_INVALID, "vk_readback: NULL argument");
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
+    const size_t row = (size_t)ctx->width * px_bytes(ctx->out_format);
+    if (row_pitch_bytes < row) return fail(ctx, VK_ERR_INVALID, "row pitch smaller than a row");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, row_pitch_bytes, ctx->backbuffer, row, row, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_step_counts(vk_ctx *ctx, uint64_t *s_ref, uint64_t *s_sampled) {
+    if (!ctx) return VK_ERR_INVALID;
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s_ref) *s_ref = h[0];
+    if (s_sampled) *s_sampled = h[1];
+    return VK_OK;
+}
+
+int vk_step_counts_reset(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    return VK_OK;
+}
+
+int vk_readback_steps(vk_ctx *ctx, uint32_t *dst) {
+    if (!ctx || !dst) return fail(ctx, VK_ERR_INVALID, "vk_readback_steps: NULL argument");
+    if (!ctx->steps) return fail(ctx, VK_ERR_INVALID, "no VK_RENDER_COUNT launch since the last resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_timer_begin(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    ctx->timing_open = true;
+    ctx->timing_done = false;
+    return VK_OK;
+}
+
+int vk_timer_end(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->timing_open) return fail(ctx, VK_ERR_INVALID, "vk_timer_end without vk_timer_begin");
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timing_open = false;
+    ctx->timing_done = true;
+    return VK_OK;
+}
+
+int vk_timer_elapsed_ms(vk_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return fail(ctx, VK_ERR_INVALID, "vk_timer_elapsed_ms: NULL argument");
+    if (!ctx->timing_done) return fail(ctx, VK_ERR_INVALID, "no completed timer bracket");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VK_OK;
+}
+
+}  // extern "C"
