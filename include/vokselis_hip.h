@@ -49,12 +49,14 @@ enum vk_out_format { VK_OUT_RGBA32F = 0, VK_OUT_RGBA16F = 1 };
 enum vk_layout {
     VK_LAYOUT_AUTO = 0,
     VK_LAYOUT_LINEAR = 1, /* x-fastest as uploaded; 8 scalar taps per sample (validation kernel) */
-    VK_LAYOUT_PACKED = 2  /* 4^3-bricked cells, each holding its 8 trilinear taps (+ skip map) */
+    VK_LAYOUT_PACKED = 2, /* 4^3-bricked cells, each holding its 8 trilinear taps (+ skip map) */
+    VK_LAYOUT_PACKED_PAIRS = 3 /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
 };
 
 enum vk_render_flags {
     VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
-    VK_RENDER_COUNT = 2     /* also accumulate step counters / per-pixel step counts */
+    VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
+    VK_RENDER_SAFE = 4      /* force the clamped / 64-bit-offset kernel variant */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */

@@ -226,7 +226,12 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
     float uy = fmaf(p[1], (float)ny, -0.5f);
     float uz = fmaf(p[2], (float)nz, -0.5f);
     float flx = floorf(ux), fly = floorf(uy), flz = floorf(uz);
+    /* fractional weights: fract(u) = min(u - floor(u), 1 - 2^-24), the GPU fract semantic
+     * (bit-identical to gfx950 v_fract_f32; checked exhaustively by tools/ubench/semantics.hip) */
     float fx = ux - flx, fy = uy - fly, fz = uz - flz;
+    if (fx >= 1.0f) fx = 0x1.fffffep-1f;
+    if (fy >= 1.0f) fy = 0x1.fffffep-1f;
+    if (fz >= 1.0f) fz = 0x1.fffffep-1f;
     /* the int conversion saturates like v_cvt_i32_f32; NaN -> 0 */
     int ix = (flx != flx) ? 0 : (flx < -2147483648.0f ? INT32_MIN : (flx >= 2147483648.0f ? INT32_MAX : (int)flx));
     int iy = (fly != fly) ? 0 : (fly < -2147483648.0f ? INT32_MIN : (fly >= 2147483648.0f ? INT32_MAX : (int)fly));

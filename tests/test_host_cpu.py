@@ -1,0 +1,138 @@
+"""CPU suite, part 2: host mirror of the reference surface and the C-ABI boundary (no GPU calls)."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol(hip_built):
+    """libvokselis_hip.so loads and exports exactly what include/vokselis_hip.h declares."""
+    from vokselis_amd import _native
+
+    hdr = open(os.path.join(ROOT, "include", "vokselis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 28
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    for name in declared:
+        assert getattr(hip_built, name) is not None
+    assert hip_built.vk_abi_version() == 1
+
+
+def test_cabi_fails_loudly_without_gpu(hip_built):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = hip_built.vk_ctx_create(0, C.byref(h))
+    assert rc == -3 and not h  # VK_ERR_NO_DEVICE, no handle, no CPU fallback
+    assert b"no HIP device" in hip_built.vk_last_error(None)
+    import vokselis_amd as V
+
+    with pytest.raises(V.VokselisError):
+        V.Context()
+
+
+def test_pure_cabi_helpers(hip_built):
+    # dispatch_optimal, src/utils/mod.rs:15-18
+    import vokselis_amd as V
+
+    for ln, sg in [(1280, 8), (720, 8), (256, 16), (1, 8), (9, 8), (0, 8), (1921, 64)]:
+        assert hip_built.vk_dispatch_optimal(ln, sg) == V.dispatch_optimal(ln, sg) == -(-ln // sg)
+    n = C.c_uint32()
+    assert hip_built.vk_partition_slots(1920, 1080, 64, 8, C.byref(n)) == 0 and n.value == 64  # 30*17 = 510 tiles
+    assert hip_built.vk_partition_slots(1920, 1080, 60, 8, C.byref(n)) != 0  # tile size must be a multiple of 8
+    assert hip_built.vk_partition_slots(1280, 720, 256, 1, C.byref(n)) == 0 and n.value == 15
+    # a NULL context is an error code, never a crash
+    assert hip_built.vk_render(None, 0, 0, 0, 8, 8, 1.0, 0) == -1
+    assert hip_built.vk_set_camera(None, None) == -1
+
+
+def test_uniform_layout_matches_reference():
+    """48-byte Uniform, src/context/global_ubo.rs:52-81."""
+    import vokselis_amd as V
+
+    u = V.Uniform()
+    b = u.to_bytes()
+    assert len(b) == 48
+    f = struct.unpack("<3fI2f2fI3f", b)
+    assert f[3] == 0 and f[4:6] == (1920.0, 780.0) and f[8] == 0
+    assert f[10] == pytest.approx(1 / 60)
+    u.frame, u.time, u.mouse_pressed, u.pos = 7, 2.5, 1, (1.0, 2.0, 3.0)
+    b = u.to_bytes()
+    assert struct.unpack_from("<I", b, 12)[0] == 7 and struct.unpack_from("<f", b, 36)[0] == 2.5
+    assert struct.unpack_from("<I", b, 32)[0] == 1 and struct.unpack_from("<3f", b, 0) == (1.0, 2.0, 3.0)
+
+
+def test_camera_matches_oracle_and_reference_semantics(O):
+    import vokselis_amd as V
+
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9)
+    assert not cam.updated  # Camera::new leaves updated = false (src/camera.rs:103)
+    assert np.allclose(cam.eye, [-0.2385, 0.0206, 0.0258], atol=1e-4)
+    blob = np.frombuffer(cam.get_proj_view_matrix(), np.float32)
+    ref = np.frombuffer(O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9), np.float32)
+    assert blob.size == 36 and blob[3] == 1.0
+    assert np.abs(blob - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+    pv, inv = blob[4:20].reshape(4, 4).T.astype(np.float64), blob[20:36].reshape(4, 4).T.astype(np.float64)
+    assert np.abs(pv @ inv - np.eye(4)).max() < 1e-4  # inv_proj = inverse(proj * view), src/camera.rs:169
+    # perspective_rh(fovy = pi/2): h = 1, w = 1/aspect
+    proj_w = np.linalg.norm(pv[0, :3])
+    assert proj_w == pytest.approx(9 / 16, rel=1e-5)
+    # setters clamp and flag like the reference (src/camera.rs:115-162)
+    cam.set_zoom(0.01); assert cam.zoom == np.float32(0.3) and cam.updated
+    cam.set_zoom(1000.0); assert cam.zoom == np.float32(50.0)
+    cam.set_pitch(10.0); assert cam.pitch < np.float32(np.pi / 2)
+    cam.add_yaw(0.25); assert cam.yaw == np.float32(1.25)
+    cam.set_aspect(1280, 720); assert cam.aspect == np.float32(1280 / 720)
+
+
+def test_image_dimentions_and_dispatch_match_oracle(O):
+    import vokselis_amd as V
+
+    for w, h in [(1280, 720), (1281, 721), (958, 1050), (1, 1), (1920, 1080), (63, 2)]:
+        d = V.ImageDimentions.new(w, h, 256)
+        out = (C.c_uint32 * 4)()
+        O.lib().vo_image_dimentions(w, h, 256, out)
+        assert (d.width, d.height, d.unpadded_bytes_per_row, d.padded_bytes_per_row) == tuple(out)
+        assert d.padded_bytes_per_row % 256 == 0 and d.linear_size() == d.padded_bytes_per_row * d.height
+    assert O.lib().vo_dispatch_optimal(1280, 8) == 160 and O.lib().vo_dispatch_optimal(720, 8) == 90  # examples/xor/main.rs:232-233
+
+
+def test_partition_bookkeeping():
+    from vokselis_amd import dist as D
+
+    for (w, h, ts, world) in [(1920, 1080, 64, 8), (1920, 1080, 64, 3), (512, 512, 64, 2), (100, 60, 16, 4), (64, 64, 64, 8)]:
+        tx, ty = D.tiles_xy(w, h, ts)
+        seen = []
+        for r in range(world):
+            lt = D.local_tiles(w, h, ts, r, world)
+            assert len(lt) <= D.n_slots(w, h, ts, world)
+            assert all(D.tile_owner(t, world) == r for t in lt)
+            seen += lt
+        assert sorted(seen) == list(range(tx * ty))  # every tile exactly once
+    # the reference's 3x6 tile enumeration for 1280x720 / TILE_SIZE 256 (examples/xor/main.rs:82-92)
+    assert (720 // 256 + 1, 1280 // 256 + 1) == (3, 6)
+
+
+def test_untile_reference_roundtrip():
+    from vokselis_amd import dist as D
+
+    rng = np.random.default_rng(3)
+    w, h, ts, world = 100, 60, 16, 3
+    frame = rng.random((h, w, 4)).astype(np.float32)
+    slots = D.n_slots(w, h, ts, world)
+    gathered = np.zeros((world, slots, ts, ts, 4), np.float32)
+    tx, _ = D.tiles_xy(w, h, ts)
+    for r in range(world):
+        for j, t in enumerate(D.local_tiles(w, h, ts, r, world)):
+            y0, x0 = (t // tx) * ts, (t % tx) * ts
+            tile = frame[y0:y0 + ts, x0:x0 + ts]
+            gathered[r, j, :tile.shape[0], :tile.shape[1]] = tile
+    assert (D.untile_reference(gathered, w, h, ts) == frame).all()

@@ -1,0 +1,152 @@
+"""CPU suite, part 1: the C oracle against the committed golden vectors and the independent numpy
+restatement.  (The reference has no tests and cannot run here: parity is unpinned -- these pin the
+two restatements to each other and to tests/golden/.)"""
+import numpy as np
+import pytest
+
+
+def _cases(npz):
+    keys = sorted({k.rsplit("__", 1)[0] for k in npz.files})
+    return keys
+
+
+def test_oracle_matches_golden_naive(O, golden, cameras, golden_volumes):
+    g = golden["naive_64x64"]
+    assert len(_cases(g)) >= 20
+    for key in _cases(g):
+        vname, cname, dts = key.split("__")
+        dt = float(dts[2:])
+        rgba, steps, samp = O.render(cameras[cname], golden_volumes[vname], 64, 64, dt_scale=dt)
+        assert np.abs(rgba - g[key + "__rgba"]).max() <= 1e-6, key
+        assert (steps == g[key + "__steps"]).all(), key
+        assert (samp == g[key + "__sampled"]).all(), key
+
+
+def test_oracle_matches_golden_f16_volume(O, golden, cameras):
+    g = golden["naive_f16_64x64"]
+    rgba, steps, _ = O.render(cameras["bonsai_1x1"], O.volume_fog_f16(32), 64, 64, dt_scale=0.5)
+    assert np.abs(rgba - g["rgba"]).max() <= 1e-6
+    assert (steps == g["steps"]).all()
+    assert steps.max() <= 2 * 32 + 1  # dt_scale 0.5 on a 32^3 volume: <= 2n+1 iterations
+
+
+def test_oracle_matches_golden_compute(O, golden, cameras):
+    g = golden["compute_128x72"]
+    den, nrm = g["density"].view(np.float16), g["normals"].view(np.float16)
+    rgba, steps, _ = O.render(cameras["xor_16x9"], den, 128, 72, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
+    assert np.abs(rgba - g["rgba"]).max() <= 1e-6
+    assert (steps == g["steps"]).all()
+    # `tile` entry point with a dynamic offset; the part beyond the image is dropped (A12)
+    t_rgba, t_steps, _ = O.render(cameras["xor_16x9"], den, 128, 72, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm,
+                                  tile=(96, 48, 64, 64))
+    assert np.abs(t_rgba - g["tile_rgba"]).max() <= 1e-6
+    assert (t_steps == g["tile_steps"]).all()
+    assert (t_rgba[:48] == 0).all() and (t_rgba[:, :96] == 0).all()  # untouched outside the tile
+    miss = steps == 0
+    assert np.allclose(rgba[miss][:, :3], [0.023, 0.02, 0.02]) and (rgba[..., 3] == 1).all()
+
+
+def test_two_restatements_agree_on_fresh_inputs(O, R):
+    """Inputs that are not in the fixtures: other sizes, non-cubic dims, other cameras / dt."""
+    for dims, cam_args, W, H, dt in [((40, 64, 24), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.5), 60, 40, 1.0),
+                                     (48, (0.8, -0.3, 4.0, (0.4, 0.5, 0.6), 1.0), 48, 48, 0.7),
+                                     (24, (2.0, 1.2, 0.3, (0.5, 0.5, 0.5), 0.75), 36, 48, 2.0)]:
+        vol = O.volume_standin_u8(dims, seed=77)
+        assert (vol == R.volume_standin_u8(dims, seed=77)).all()
+        cam = O.camera_blob(*cam_args)
+        a, sa, ma = O.render(cam, vol, W, H, dt_scale=dt)
+        b, sb, mb = R.render_naive(cam, vol, W, H, dt_scale=dt)
+        assert np.abs(a - b).max() <= 1e-6
+        assert (sa == sb).all() and (ma == mb).all()
+        assert sa.sum() > 0
+
+
+def test_units_intersect_box(O, golden):
+    import ctypes as C
+    u = golden["units"]
+    for o, d, t0, t1 in zip(u["box_o"], u["box_d"], u["box_t0"], u["box_t1"]):
+        out = (C.c_float * 2)()
+        O.lib().vo_intersect_box((C.c_float * 3)(*o), (C.c_float * 3)(*d), 0.0, 1.0, out)
+        assert np.float32(out[0]) == t0 or (np.isnan(out[0]) and np.isnan(t0))
+        assert np.float32(out[1]) == t1 or (np.isnan(out[1]) and np.isnan(t1))
+    # axis-parallel ray through the box: +-inf slabs on the degenerate axes, finite on z
+    out = (C.c_float * 2)()
+    O.lib().vo_intersect_box((C.c_float * 3)(0.5, 0.5, -1.0), (C.c_float * 3)(0.0, 0.0, 1.0), 0.0, 1.0, out)
+    assert (out[0], out[1]) == (1.0, 2.0)
+    # eye inside the box: t0 < 0 before the max(t0, 0)
+    O.lib().vo_intersect_box((C.c_float * 3)(0.5, 0.5, 0.5), (C.c_float * 3)(0.0, -1.0, 0.0), 0.0, 1.0, out)
+    assert out[0] == -0.5 and out[1] == 0.5
+    # box behind the ray: the slab test still reports t0 < t1 (both negative); after max(t0, 0)
+    # the march loop runs zero times, so the pixel is black like a miss (raycast_naive.wgsl:91-101)
+    O.lib().vo_intersect_box((C.c_float * 3)(2.0, 2.0, 2.0), (C.c_float * 3)(0.57735026, 0.57735026, 0.57735026), 0.0, 1.0, out)
+    assert out[0] < out[1] < 0
+    # true miss: slabs do not overlap
+    O.lib().vo_intersect_box((C.c_float * 3)(2.0, 2.0, 0.5), (C.c_float * 3)(0.0, -1.0, 0.0), 0.0, 1.0, out)
+    assert out[0] > out[1]
+
+
+def test_units_trilinear_clamp_to_edge(O, golden, golden_volumes):
+    import ctypes as C
+    u = golden["units"]
+    ramp, stand = golden_volumes["ramp_x"], golden_volumes["standin"]
+    for p, e_ramp, e_stand in zip(u["tri_pts"], u["tri_ramp_x"], u["tri_standin"]):
+        pp = (C.c_float * 3)(*p)
+        got = O.lib().vo_sample_trilinear(ramp.ctypes.data, 32, 32, 32, O.FMT_R8_UNORM, pp, 0, None)
+        assert abs(got - e_ramp) <= 1e-7
+        got = O.lib().vo_sample_trilinear(stand.ctypes.data, 32, 32, 32, O.FMT_R8_UNORM, pp, 0, None)
+        assert abs(got - e_stand) <= 1e-7
+    # texel centre returns the texel; outside the first/last centre the edge texel is held
+    v = ramp
+    centre = (C.c_float * 3)((5 + 0.5) / 32, 0.5, 0.5)
+    assert O.lib().vo_sample_trilinear(v.ctypes.data, 32, 32, 32, 0, centre, 0, None) == pytest.approx(v[0, 0, 5] / 255, abs=1e-7)
+    for x, ref in ((0.0, v[0, 0, 0]), (0.2 / 32, v[0, 0, 0]), (1.0, v[0, 0, 31]), (31.9 / 32, v[0, 0, 31])):
+        got = O.lib().vo_sample_trilinear(v.ctypes.data, 32, 32, 32, 0, (C.c_float * 3)(x, 0.5, 0.5), 0, None)
+        assert got == pytest.approx(ref / 255, abs=1e-7)
+
+
+def test_units_srgb_and_transfer(O, golden):
+    u = golden["units"]
+    for x, y in zip(u["srgb_x"], u["srgb_y"]):
+        assert abs(O.lib().vo_linear_to_srgb(float(x)) - y) <= 2e-7
+    assert O.lib().vo_linear_to_srgb(0.0031308) == pytest.approx(12.92 * 0.0031308, rel=1e-6)  # the knee
+    for r, a in zip(u["alpha_r"], u["alpha_a"]):
+        assert O.lib().vo_transfer_alpha(float(r)) == a
+    # u8 <= 25 is exactly transparent, 26 is not; opacity saturates at min(0.9, r)
+    inv255 = np.float32(1.0) / np.float32(255.0)
+    assert O.lib().vo_transfer_alpha(float(np.float32(25) * inv255)) == 0.0
+    assert O.lib().vo_transfer_alpha(float(np.float32(26) * inv255)) > 0.0
+    amax = O.lib().vo_transfer_alpha(1.0)
+    assert amax == O.lib().vo_transfer_alpha(0.9) and amax == pytest.approx(0.8174, abs=2e-4)
+
+
+def test_tap_normalisation_order_is_immaterial(O, cameras, golden_volumes):
+    """The specification normalises R8Unorm once after filtering; normalising each tap first (the
+    literal reading of the sampler) changes the image by far less than the 1e-4 budget."""
+    for name in ("standin", "ramp_y"):
+        a, sa, _ = O.render(cameras["bonsai_1x1"], golden_volumes[name], 64, 64)
+        b, sb, _ = O.render(cameras["bonsai_1x1"], golden_volumes[name], 64, 64, flags=O.FLAG_TAPNORM_PER_TAP)
+        same = sa == sb
+        assert same.mean() > 0.995  # an early-out can flip by one step on a handful of rays
+        assert np.abs(a - b)[same].max() <= 2e-6
+
+
+def test_f16_conversions(O):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(5000).astype(np.float32) * 10.0 ** rng.integers(-8, 5, 5000),
+                        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 6e-8, 2.98e-8, 2.99e-8, np.inf, -np.inf, 0.7], np.float32)])
+    want = x.astype(np.float16).view(np.uint16)
+    got = np.array([O.lib().vo_f32_to_f16(float(v)) for v in x], np.uint16)
+    assert (got == want).all()
+    h = np.arange(0, 65536, 7, dtype=np.uint16)
+    back = np.array([O.lib().vo_f16_to_f32(int(v)) for v in h], np.float32)
+    ref = h.view(np.float16).astype(np.float32)
+    assert ((back == ref) | (np.isnan(back) & np.isnan(ref))).all()
+
+
+def test_nominal_step_counts_match_survey(O, cameras):
+    """512x512 dt 1.0 -> 54.3 % hit, 2.16e7 nominal steps, <= 257 per ray."""
+    vol = np.zeros((256, 256, 256), np.uint8)
+    _, steps, _ = O.render(cameras["bonsai_1x1"], vol, 512, 512, dt_scale=1.0, flags=O.FLAG_NO_EARLY_OUT)
+    assert abs((steps > 0).mean() - 0.543) < 0.002
+    assert abs(steps.sum() / 2.16e7 - 1) < 0.01
+    assert steps.max() == 257

@@ -1,0 +1,308 @@
+"""GPU suite: the HIP path, called through the C-ABI, against the CPU oracle and the golden vectors.
+
+Bars: per-channel |dRGBA| <= 1e-4 on the f32 surface (north star); loop trip counts (S_ref) and
+the count of tap-fetching steps (S_sampled) are integer work and must be *identical*.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def V(hip_built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU: the gpu suite must run on an MI355X box")
+    import vokselis_amd
+
+    return vokselis_amd
+
+
+def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None, tile=None, vol2=None, mode=None,
+               want_steps=True):
+    out = V.OUT_RGBA32F if out is None else out
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=out)
+    try:
+        V.VolumeTexture(ctx, vol, vol2, layout=V.LAYOUT_AUTO if layout is None else layout)
+        ctx.set_camera_blob(cam_blob)
+        ctx.reset_step_counts()
+        pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR if mode is None else mode, dt_scale=dt,
+                                 flags=flags | (V.RENDER_COUNT if want_steps else 0))
+        pipe.record(ctx, tile)
+        img = ctx.read_backbuffer()
+        steps = ctx.read_steps() if want_steps else None
+        counts = ctx.step_counts() if want_steps else None
+        return img, steps, counts
+    finally:
+        ctx.close()
+
+
+def layouts(V):
+    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR}
+
+
+# ---------------------------------------------------------------------------------------------
+
+
+def test_golden_vectors_every_layout(V, golden, cameras, golden_volumes):
+    g = golden["naive_64x64"]
+    keys = sorted({k.rsplit("__", 1)[0] for k in g.files})
+    for key in keys:
+        vname, cname, dts = key.split("__")
+        for lname, lay in layouts(V).items():
+            img, steps, (s_ref, s_samp) = gpu_render(V, cameras[cname], golden_volumes[vname], 64, 64, dt=float(dts[2:]), layout=lay)
+            assert np.abs(img - g[key + "__rgba"]).max() <= TOL, (key, lname)
+            assert (steps == g[key + "__steps"]).all(), (key, lname)
+            assert s_ref == int(g[key + "__steps"].astype(np.int64).sum())
+            if lname != "LIN":  # exact empty-space skipping fetches taps only where a tap can contribute
+                assert s_samp == int(g[key + "__sampled"].astype(np.int64).sum()), (key, lname)
+
+
+@pytest.mark.parametrize("W,H,dt,aspect", [(512, 512, 1.0, 1.0), (1920, 1080, 0.5, 16 / 9)])
+def test_bonsai_standin_full_frame(V, O, W, H, dt, aspect):
+    """BASELINE configs C1 and C2 on the 256^3 stand-in, every pixel, against the oracle."""
+    vol = O.volume_standin_u8(256)
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), aspect).get_proj_view_matrix()
+    ref, rsteps, rsamp = O.render(cam, vol, W, H, dt_scale=dt)
+    for lay in (V.LAYOUT_PACKED_PAIRS, V.LAYOUT_PACKED):
+        img, steps, (s_ref, s_samp) = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay)
+        assert np.abs(img - ref).max() <= TOL
+        assert (steps == rsteps).all()
+        assert s_ref == int(rsteps.sum()) and s_samp == int(rsamp.sum())
+        assert (img[..., 3] == 1).all()
+    miss = rsteps == 0
+    assert (img[miss][:, :3] == 0).all()  # clear colour BLACK, alpha 1 (examples/bonsai/main.rs:41)
+
+
+def test_skip_is_exact(V, O):
+    """Size-independent property: skipping changes no pixel bit and no trip count."""
+    vol = O.volume_standin_u8(256)
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9).get_proj_view_matrix()
+    a, sa, (ra, ma) = gpu_render(V, cam, vol, 1920, 1080, dt=0.5, layout=V.LAYOUT_PACKED_PAIRS)
+    b, sb, (rb, mb) = gpu_render(V, cam, vol, 1920, 1080, dt=0.5, layout=V.LAYOUT_PACKED_PAIRS, flags=V.RENDER_NO_SKIP)
+    c, sc, _ = gpu_render(V, cam, vol, 1920, 1080, dt=0.5, layout=V.LAYOUT_PACKED_PAIRS, flags=V.RENDER_SAFE)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all() and (a.view(np.uint32) == c.view(np.uint32)).all()
+    assert (sa == sb).all() and (sa == sc).all() and ra == rb
+    assert ma < mb == rb  # without skipping every iteration fetches taps
+
+
+def test_fog_never_terminates_early(V, O):
+    """C2-fog: alpha/step <= 1.4e-3, so S_ref == S_nominal."""
+    vol = O.volume_fog_u8(256)
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9).get_proj_view_matrix()
+    img, steps, (s_ref, _) = gpu_render(V, cam, vol, 1920, 1080, dt=0.5)
+    ref, rsteps, _ = O.render(cam, vol, 1920, 1080, dt_scale=0.5)
+    _, nsteps, _ = O.render(cam, vol, 1920, 1080, dt_scale=0.5, flags=O.FLAG_NO_EARLY_OUT, want_counts=True)
+    assert (steps == rsteps).all() and (rsteps == nsteps).all()
+    assert np.abs(img - ref).max() <= TOL
+    assert abs(s_ref / 1.92e8 - 1) < 0.01 and steps.max() == 513
+
+
+def test_rgba16f_surface(V, O, cameras, golden_volumes):
+    """The reference-shaped rgba16float backbuffer: RNE of the f32 result.  Colour
+    differs from the oracle in the last f32 ulps, so a value may land on the other side of an f16
+    rounding boundary: allow one f16 ulp, require almost all pixels identical."""
+    vol = golden_volumes["standin"]
+    ref, _, _ = O.render(cameras["bonsai_1x1"], vol, 64, 64)
+    want = O.rgba32f_to_rgba16f(ref)
+    img, _, _ = gpu_render(V, cameras["bonsai_1x1"], vol, 64, 64, out=V.OUT_RGBA16F)
+    got = img.view(np.uint16)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.995
+    assert (got[..., 3] == 0x3C00).all()
+
+
+def test_tiles_and_offscreen(V, O, cameras, golden_volumes):
+    """Tile rectangles (A12): any origin, partially or wholly off-screen, compose to the frame."""
+    vol = golden_volumes["standin"]
+    W, H = 100, 76
+    cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+    ref, rsteps, _ = O.render(cam, vol, W, H)
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture(ctx, vol)
+        ctx.set_camera_blob(cam)
+        pipe = V.RaycastPipeline(dt_scale=1.0)
+        for ty in range(-16, H + 16, 40):      # 40x40 tiles from a negative origin
+            for tx in range(-16, W + 16, 40):
+                pipe.record(ctx, (tx, ty, 40, 40))
+        pipe.record(ctx, (W + 5, 3, 40, 40))  # wholly off-screen: dropped
+        img = ctx.read_backbuffer()
+        assert np.abs(img - ref).max() <= TOL
+        # a single interior tile leaves the rest of the (cleared) backbuffer alone
+        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+        pipe.record(ctx, (30, 20, 17, 9))
+        img = ctx.read_backbuffer()
+        mask = np.zeros((H, W), bool); mask[20:29, 30:47] = True
+        assert np.abs(img[mask] - ref[mask]).max() <= TOL
+        assert (img[~mask] == [0, 0, 0, 1]).all()
+    finally:
+        ctx.close()
+
+
+def test_partition_untile_equals_frame(V, O):
+    """Multi-GPU scheme on one GPU: every rank's partition, concatenated, un-tiles to the frame."""
+    from vokselis_amd import dist as D
+
+    vol = O.volume_standin_u8(64)
+    W, H, ts = 200, 136, 32
+    cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+    ref, _, _ = O.render(cam, vol, W, H, dt_scale=0.5)
+    import torch
+
+    for world in (1, 2, 3, 8):
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture(ctx, vol)
+            ctx.set_camera_blob(cam)
+            slots = V.partition_slots(W, H, ts, world)
+            gathered = torch.zeros((world, slots, ts, ts, 4), dtype=torch.float32, device="cuda")
+            pipe = V.RaycastPipeline(dt_scale=0.5)
+            for r in range(world):
+                pipe.record_partition(ctx, ts, r, world, gathered[r].data_ptr())
+            ctx.sync()
+            host = D.untile_reference(gathered.cpu().numpy(), W, H, ts)
+            assert np.abs(host - ref).max() <= TOL
+            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world))
+            img = ctx.read_backbuffer()
+            assert (img == host).all()
+        finally:
+            ctx.close()
+
+
+def test_f16_volume(V, O, golden, cameras):
+    g = golden["naive_f16_64x64"]
+    vol = O.volume_fog_f16(32)
+    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
+        img, steps, _ = gpu_render(V, cameras["bonsai_1x1"], vol, 64, 64, dt=0.5, layout=lay)
+        assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
+    # a dense-core f16 volume exercises the early-out and the skip map's 0.1 threshold
+    z, y, x = np.meshgrid(np.arange(48), np.arange(48), np.arange(48), indexing="ij")
+    r2 = (x - 24) ** 2 + (y - 20) ** 2 + (z - 28) ** 2
+    core = np.where(r2 < 100, 0.95, np.where(r2 < 400, 0.3, 0.05)).astype(np.float16)
+    ref, rsteps, rsamp = O.render(cameras["bonsai_1x1"], core, 96, 96, dt_scale=0.5)
+    img, steps, (s_ref, s_samp) = gpu_render(V, cameras["bonsai_1x1"], core, 96, 96, dt=0.5)
+    assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all() and s_samp == int(rsamp.sum())
+
+
+def test_device_fog_generator_is_bit_identical(V, O):
+    cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
+    for fmt, host in ((V.FMT_R8_UNORM, O.volume_fog_u8((40, 24, 56), seed=99, lo=20, span=12)),
+                      (V.FMT_R16_FLOAT, O.volume_fog_f16((40, 24, 56), seed=99))):
+        ref, rsteps, _ = O.render(cam, host, 80, 80, dt_scale=0.5)
+        ctx = V.Context(80, 80, backbuffer=(80, 80), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture.generate_fog(ctx, (40, 24, 56), fmt=fmt, seed=99)
+            ctx.set_camera_blob(cam)
+            V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)
+            assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL and (ctx.read_steps() == rsteps).all()
+        finally:
+            ctx.close()
+
+
+def test_cameras_dims_and_dt(V, O):
+    """Non-cubic dims, eye inside the volume, grazing and axis-aligned views, several dt_scale."""
+    rng = np.random.default_rng(11)
+    for dims, cam_args, W, H, dt in [((40, 64, 24), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.5), 120, 80, 1.0),
+                                     ((96, 32, 48), (0.8, -0.3, 4.0, (0.4, 0.5, 0.6), 1.0), 96, 96, 0.7),
+                                     ((64, 64, 64), (0.31, 0.2, 2.5, (0.5, 0.5, 0.5), 1.0), 80, 80, 0.25),
+                                     ((33, 17, 65), (2.0, 1.2, 0.3, (0.5, 0.5, 0.5), 0.75), 60, 80, 2.0),
+                                     ((64, 64, 64), (1.5, 0.0, 0.0, (0.5, 0.5, 0.5), 1.0), 64, 64, 1.0),
+                                     ((1, 1, 1), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 32, 32, 0.5),
+                                     ((2, 3, 5), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 32, 32, 0.1)]:
+        nx, ny, nz = dims
+        vol = (O.volume_standin_u8(dims, seed=5) if min(dims) >= 17 else rng.integers(0, 256, (nz, ny, nx)).astype(np.uint8))
+        cam = O.camera_blob(*cam_args)
+        ref, rsteps, rsamp = O.render(cam, vol, W, H, dt_scale=dt)
+        for lay in (V.LAYOUT_PACKED_PAIRS, V.LAYOUT_PACKED):
+            for fl in (0, V.RENDER_SAFE):
+                img, steps, (_, s_samp) = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay, flags=fl)
+                assert np.abs(img - ref).max() <= TOL, (dims, lay, fl)
+                assert (steps == rsteps).all(), (dims, lay, fl)
+                assert s_samp == int(rsamp.sum())
+
+
+def test_compute_nearest_mode(V, O, golden, cameras):
+    """raycast_compute.wgsl `single` and `tile` (A10-A12) against the golden vectors."""
+    g = golden["compute_128x72"]
+    den, nrm = g["density"].view(np.float16), g["normals"].view(np.float16)
+    img, steps, _ = gpu_render(V, cameras["xor_16x9"], den, 128, 72, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST)
+    assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
+    # the reference's tile loop: (H/256+1) x (W/256+1) offsets, here with 64-px tiles incl. off-screen ones
+    ctx = V.Context(128, 72, backbuffer=(128, 72), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture(ctx, den, nrm)
+        ctx.set_camera_blob(cameras["xor_16x9"])
+        pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST)
+        for y in range(72 // 64 + 1):
+            for x in range(128 // 64 + 1):
+                pipe.record(ctx, (x * 64, y * 64, 64, 64))
+        assert np.abs(ctx.read_backbuffer() - g["rgba"]).max() <= TOL
+    finally:
+        ctx.close()
+
+
+def test_error_behaviour(V, O, cameras, golden_volumes):
+    ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
+    try:
+        pipe = V.RaycastPipeline()
+        with pytest.raises(V.VokselisError, match="no volume"):
+            pipe.record(ctx)
+        V.VolumeTexture(ctx, golden_volumes["standin"])
+        with pytest.raises(V.VokselisError, match="no camera"):
+            pipe.record(ctx)
+        ctx.set_camera_blob(cameras["bonsai_1x1"])
+        with pytest.raises(V.VokselisError, match="dt_scale"):
+            V.RaycastPipeline(dt_scale=0.0).record(ctx)
+        with pytest.raises(V.VokselisError, match="COMPUTE_NEAREST"):
+            V.RaycastPipeline(V.MODE_COMPUTE_NEAREST).record(ctx)
+        bad = np.frombuffer(cameras["bonsai_1x1"], np.float32).copy(); bad[5] = np.nan
+        with pytest.raises(V.VokselisError, match="non-finite"):
+            ctx.set_camera_blob(bad.tobytes())
+        with pytest.raises(V.VokselisError, match="no camera"):  # a rejected blob does not linger
+            pipe.record(ctx)
+        ctx.set_camera_blob(cameras["bonsai_1x1"])
+        pipe.record(ctx, (0, 0, 0, 0))  # empty tile is a no-op
+        info = ctx.get_info()
+        assert info["gfx950"] and info["compute_units"] == 256
+    finally:
+        ctx.close()
+
+
+def test_headless_demo_loop(V, O):
+    """The reference's frame order: Context.update -> Demo.update -> Demo.render (src/lib.rs:75-79,178-181)."""
+    vol = O.volume_standin_u8(64)
+    calls = []
+
+    class Bonsai(V.Demo):
+        @classmethod
+        def init(cls, ctx):
+            self = cls()
+            self.volume_texture = V.VolumeTexture(ctx, vol)
+            self.pipeline = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=1.0)
+            calls.append("init")
+            return self
+
+        def update(self, ctx):
+            calls.append("update")
+
+        def render(self, ctx):
+            calls.append("render")
+            self.pipeline.record(ctx)
+
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 160 / 90)
+    ctx, demo = V.run_headless(Bonsai, frames=3, camera=cam, width=160, height=90, backbuffer=(160, 90), out_format=V.OUT_RGBA32F)
+    try:
+        assert calls == ["init"] + ["update", "render"] * 3
+        ref, _, _ = O.render(cam.get_proj_view_matrix(), vol, 160, 90)
+        assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL
+        buf, dims = ctx.capture_frame()
+        assert len(buf) == dims.linear_size() and dims.padded_bytes_per_row == 768
+    finally:
+        ctx.close()

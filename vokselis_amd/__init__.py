@@ -9,7 +9,7 @@ Only the raycast hot path and the host surface that drives it live here (SURVEY.
   dist       tile-parallel multi-GPU frame (one process per GPU, RCCL gather over xGMI)
 """
 from . import _native as native
-from ._native import (FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR, LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED,
+from ._native import (FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR, LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, RENDER_SAFE,
                       MODE_COMPUTE_NEAREST, MODE_NAIVE_TRILINEAR, OUT_RGBA16F, OUT_RGBA32F, RENDER_COUNT,
                       RENDER_NO_SKIP, VokselisError)
 from .camera import Camera
@@ -19,6 +19,6 @@ from .context import (Context, Demo, FrameCounter, HdrBackBuffer, ImageDimention
 __all__ = [
     "native", "Camera", "Context", "Demo", "FrameCounter", "HdrBackBuffer", "ImageDimentions", "RaycastPipeline",
     "Uniform", "VolumeTexture", "dispatch_optimal", "partition_slots", "run_headless", "VokselisError",
-    "FMT_R8_UNORM", "FMT_R16_FLOAT", "FMT_RGBA16F_PAIR", "LAYOUT_AUTO", "LAYOUT_LINEAR", "LAYOUT_PACKED",
+    "FMT_R8_UNORM", "FMT_R16_FLOAT", "FMT_RGBA16F_PAIR", "LAYOUT_AUTO", "LAYOUT_LINEAR", "LAYOUT_PACKED", "LAYOUT_PACKED_PAIRS", "RENDER_SAFE",
     "MODE_COMPUTE_NEAREST", "MODE_NAIVE_TRILINEAR", "OUT_RGBA16F", "OUT_RGBA32F", "RENDER_COUNT", "RENDER_NO_SKIP",
 ]

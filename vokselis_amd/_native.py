@@ -14,8 +14,8 @@ VK_OK = 0
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
 MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED = 0, 1, 2
-RENDER_NO_SKIP, RENDER_COUNT = 1, 2
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS = 0, 1, 2, 3
+RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE = 1, 2, 4
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
 _u32, _i32, _f32, _vp, _sz = C.c_uint32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t

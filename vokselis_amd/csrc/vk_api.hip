@@ -28,6 +28,8 @@ struct vk_ctx {
     size_t vol_bytes = 0;
     uint32_t nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     int format = -1, layout = 0;
+    int vol_kind = -1;  // vk::VolKind
+    VolumeDesc vdesc{};
 
     // uniforms (host copies; passed to kernels by value)
     unsigned char uniform[48] = {0};
@@ -186,43 +188,60 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
             }
         }
         ctx->vol_bytes = n_vox * bpv * (d_src2 ? 2 : 1);
+        ctx->vol_kind = format == VK_FMT_R16_FLOAT ? VOL_LINEAR_F16 : VOL_LINEAR_U8;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return VK_OK;
     }
-    // PACKED: (n+1) cells per axis, rounded up to whole 4^3 bricks
+    // PACKED: cells for low-corner voxels i in [-1, n-1]; physical brick (i >> 2) + 1
     const bool f16 = format == VK_FMT_R16_FLOAT;
-    ctx->nbx = (nx + 1 + kBrick - 1) / kBrick;
-    ctx->nby = (ny + 1 + kBrick - 1) / kBrick;
-    ctx->nbz = (nz + 1 + kBrick - 1) / kBrick;
+    if (f16 && layout == VK_LAYOUT_PACKED_PAIRS)
+        return fail(ctx, VK_ERR_UNSUPPORTED, "PACKED_PAIRS stores exact u8 differences; f16 volumes use PACKED");
+    const int kind = f16 ? VOL_PF16 : (layout == VK_LAYOUT_PACKED_PAIRS ? VOL_P16 : VOL_P8);
+    ctx->nbx = ((nx - 1) >> 2) + 2;
+    ctx->nby = ((ny - 1) >> 2) + 2;
+    ctx->nbz = ((nz - 1) >> 2) + 2;
     const uint64_t n_bricks = (uint64_t)ctx->nbx * ctx->nby * ctx->nbz;
     const uint64_t n_cells = n_bricks * kBrickCells;
-    const size_t cell_bytes = f16 ? 16 : 8;
+    const size_t cell_bytes = kind == VOL_P8 ? 8 : 16;
     if (n_bricks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for 32-bit brick indices");
+    if (n_cells >= (1ull << 40)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large");
     HIP_TRY(ctx, hipMalloc(&ctx->vol, n_cells * cell_bytes));
     uint8_t *tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&ctx->dist, n_bricks));
-    HIP_TRY(ctx, hipMalloc(&tmp, n_bricks));
-    ctx->vol_bytes = n_cells * cell_bytes + n_bricks;
-    const uint32_t pack_blocks = (uint32_t)((n_cells + 255) / 256);
-    if (f16) {
-        hipLaunchKernelGGL(pack_cells_kernel<true>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
-        hipLaunchKernelGGL(brick_occupancy_kernel<true>, dim3((uint32_t)n_bricks), dim3(64), 0, ctx->stream, ctx->vol, ctx->dist, n_bricks);
-    } else {
-        hipLaunchKernelGGL(pack_cells_kernel<false>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
-        hipLaunchKernelGGL(brick_occupancy_kernel<false>, dim3((uint32_t)n_bricks), dim3(64), 0, ctx->stream, ctx->vol, ctx->dist, n_bricks);
-    }
-    const uint32_t db = (uint32_t)((n_bricks + 255) / 256);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 0, 0);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, tmp, ctx->dist, ctx->nbx, ctx->nby, ctx->nbz, 1, 0);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(db), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 2, 1);
+    HIP_TRY(ctx, hipMalloc(&ctx->dist, n_cells));
+    HIP_TRY(ctx, hipMalloc(&tmp, n_cells));
+    ctx->vol_bytes = n_cells * cell_bytes + n_cells;
+    ctx->vol_kind = kind;
+    const uint64_t pack_blocks64 = (n_cells + 255) / 256;
+    if (pack_blocks64 >= (1ull << 31)) { (void)hipFree(tmp); return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for one launch"); }
+    const uint32_t pack_blocks = (uint32_t)pack_blocks64;
+    if (kind == VOL_PF16)
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_PF16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
+    else if (kind == VOL_P16)
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_P16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
+    else
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_P8>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 0, 0);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, tmp, ctx->dist, ctx->nbx, ctx->nby, ctx->nbz, 1, 0);
+    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 2, 1);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { (void)hipFree(tmp); return fail(ctx, VK_ERR_HIP, std::string("volume re-layout launch: ") + hipGetErrorString(le)); }
-    hipError_t ce = hipMemcpyAsync(ctx->dist, tmp, n_bricks, hipMemcpyDeviceToDevice, ctx->stream);
+    hipError_t ce = hipMemcpyAsync(ctx->dist, tmp, n_cells, hipMemcpyDeviceToDevice, ctx->stream);
     hipError_t se = hipStreamSynchronize(ctx->stream);
     (void)hipFree(tmp);
     if (own_src) { (void)hipFree(const_cast<void *>(d_src)); }
     if (ce != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("dist copy: ") + hipGetErrorString(ce));
     if (se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("volume re-layout: ") + hipGetErrorString(se));
+    // addressing constants (vk_kernels.hpp: VolumeDesc)
+    VolumeDesc &V = ctx->vdesc;
+    const int64_t cb = (int64_t)cell_bytes, bxn = ctx->nbx, bxyn = (int64_t)ctx->nbx * ctx->nby;
+    V.sh_x = cell_bytes == 8 ? 3 : 4;
+    V.sh_y = V.sh_x + 2;
+    V.sh_z = V.sh_x + 4;
+    V.kx = (int32_t)(60 * cb);
+    V.ky = (int32_t)((64 * bxn - 16) * cb);
+    V.kz = (64 * bxyn - 64) * cb;
+    V.c0 = (64 * bxyn + 64 * bxn + 64) * cb;
+    V.max_off = (int64_t)(n_cells - 1) * cb;
     return VK_OK;
 }
 
@@ -234,7 +253,7 @@ static int check_volume_args(vk_ctx *ctx, const void *p, const void *p2, uint32_
         return fail(ctx, VK_ERR_INVALID, "volume dims must be in [1, 8192]");
     if (format < VK_FMT_R8_UNORM || format > VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_INVALID, "unknown volume format");
     if (format == VK_FMT_RGBA16F_PAIR && !p2) return fail(ctx, VK_ERR_INVALID, "RGBA16F_PAIR needs the normals volume");
-    if (layout < VK_LAYOUT_AUTO || layout > VK_LAYOUT_PACKED) return fail(ctx, VK_ERR_INVALID, "unknown layout");
+    if (layout < VK_LAYOUT_AUTO || layout > VK_LAYOUT_PACKED_PAIRS) return fail(ctx, VK_ERR_INVALID, "unknown layout");
     return VK_OK;
 }
 
@@ -365,16 +384,22 @@ int vk_backbuffer_clear(vk_ctx *ctx) {
 
 }  // extern "C"
 
-template <int VOL, bool SKIP>
+template <int VOL, bool SKIP, bool SAFE>
 static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (f16) {
-        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
     } else {
-        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
     }
+}
+
+template <int VOL>
+static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count, bool skip, bool safe) {
+    if (skip) { if (safe) launch_naive<VOL, true, true>(ctx, L, V, grid, count); else launch_naive<VOL, true, false>(ctx, L, V, grid, count); }
+    else { if (safe) launch_naive<VOL, false, true>(ctx, L, V, grid, count); else launch_naive<VOL, false, false>(ctx, L, V, grid, count); }
 }
 
 static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
@@ -429,7 +454,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.out = compact_out ? compact_out : ctx->backbuffer;
     L.steps = count ? ctx->steps : nullptr;
     L.counters = count ? ctx->counters : nullptr;
-    VolumeDesc V{};
+    VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
@@ -445,13 +470,23 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         }
     } else {
         const bool skip = !(flags & VK_RENDER_NO_SKIP);
-        const bool f16v = ctx->format == VK_FMT_R16_FLOAT;
-        if (ctx->layout == VK_LAYOUT_PACKED) {
-            if (f16v) { if (skip) launch_naive<VOL_PACKED_F16, true>(ctx, L, V, grid, count); else launch_naive<VOL_PACKED_F16, false>(ctx, L, V, grid, count); }
-            else { if (skip) launch_naive<VOL_PACKED_U8, true>(ctx, L, V, grid, count); else launch_naive<VOL_PACKED_U8, false>(ctx, L, V, grid, count); }
-        } else {
-            if (f16v) launch_naive<VOL_LINEAR_F16, false>(ctx, L, V, grid, count);
-            else launch_naive<VOL_LINEAR_U8, false>(ctx, L, V, grid, count);
+        // SAFE=false (no per-axis clamps, 32-bit offsets) only when both are provably harmless:
+        // the cell array is < 2 GiB, and the camera is near enough that the accumulated position
+        // stays within 0.5/n of the box (|p error| <= ~64 ulp(reach) << 0.5/n).
+        bool safe = true;
+        {
+            const float *e = ctx->camera;
+            float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
+            float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
+            float ulp = std::nextafter(reach, 2.0f * reach) - reach;
+            if (V.max_off + 16 < (1ll << 31) && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
+        }
+        switch (ctx->vol_kind) {
+            case VOL_P8: launch_packed<VOL_P8>(ctx, L, V, grid, count, skip, safe); break;
+            case VOL_P16: launch_packed<VOL_P16>(ctx, L, V, grid, count, skip, safe); break;
+            case VOL_PF16: launch_packed<VOL_PF16>(ctx, L, V, grid, count, skip, safe); break;
+            case VOL_LINEAR_F16: launch_naive<VOL_LINEAR_F16, false, true>(ctx, L, V, grid, count); break;
+            default: launch_naive<VOL_LINEAR_U8, false, true>(ctx, L, V, grid, count); break;
         }
     }
     HIP_TRY(ctx, hipGetLastError());

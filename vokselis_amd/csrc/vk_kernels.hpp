@@ -20,22 +20,30 @@ namespace vk {
 // stores that footprint's 8 taps contiguously: 8 B (u8) or 16 B (f16), tap b = dx + 2*dy + 4*dz.
 // One trilinear sample is therefore ONE aligned 8/16-byte load -- exactly the algorithmic
 // B_step of SURVEY 8(d).  Cells are grouped in 4x4x4 bricks (512 B / 1 KiB = 4 / 8 cache lines)
-// so a wave's 8x8 ray bundle touches a handful of lines whatever the ray direction.  A u8 map
-// with one entry per brick holds the Chebyshev distance (in bricks) to the nearest brick that
-// has any tap above the transfer function's zero threshold; it drives exact empty-space skipping.
+// so a wave's 8x8 ray bundle touches a handful of lines whatever the ray direction.  A u8 map in
+// the same cell order (one 64 B line per brick) holds each cell's Chebyshev distance, in cells,
+// to the nearest cell that has any tap above the transfer function's zero threshold (0 = this
+// cell contributes); it drives exact empty-space skipping.
 constexpr int kBrick = 4;
 constexpr int kBrickCells = 64;
-constexpr int kDistRadius = 32;  // distance map saturates at kDistRadius + 1
+constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
 
-enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_PACKED_U8 = 2, VOL_PACKED_F16 = 3 };
+// P8: 8 u8 taps (8 B).  P16: u8 volume as 4 x (tap, delta = next_x_tap - tap) f16 pairs (16 B).
+// PF16: f16 volume, 8 f16 taps (16 B).
+enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4 };
 enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 
 struct VolumeDesc {
     const void *data;     // cells (PACKED) or dense voxels (LINEAR); PAIR: density rgba16f
     const void *data2;    // PAIR: normals rgba16f
-    const uint8_t *dist;  // PACKED: brick distance map
+    const uint8_t *dist;  // PACKED: per-cell distance map (same index as the cells)
     uint32_t nx, ny, nz;  // voxel dims
     uint32_t nbx, nby, nbz;  // brick grid dims
+    // byte offset of the cell with low-corner voxel (ix,iy,iz), b = i >> 2:
+    //   c0 + bx*kx + by*ky + bz*kz + (ix << sh_x) + (iy << sh_y) + (iz << sh_z)
+    int64_t kz, c0, max_off;
+    int32_t kx, ky;
+    uint32_t sh_x, sh_y, sh_z;
 };
 
 struct LaunchDesc {
@@ -177,8 +185,31 @@ __device__ __forceinline__ float trilerp(const float t[8], float fx, float fy, f
 }
 
 // ---- NAIVE_TRILINEAR: raycast_naive.wgsl:83-125 ----------------------------------------------
-template <int VOL, bool SKIP, int OUT, bool COUNT>
+// The loop is VALU-issue bound on gfx950 (~4.4 cycles per wave64 VALU instruction at 8 waves/SIMD,
+// tools/ubench/valu_rate.hip), so the kernel is written for instruction count:
+//  * v_cvt_flr_i32_f32 + v_fract_f32 give the cell index and the lerp weight in 2 ops per axis;
+//  * brick addressing is three multiply-adds: with b = i >> 2, the cell index
+//    ((Bz*nby + By)*nbx + Bx)*64 + wz*16 + wy*4 + wx  (B = b+1, w = i - 4b) is affine in (i, b);
+//  * P16 cells hold (tap, delta) f16 pairs so an x-lerp is one v_fma_mix_f32, no unpack;
+//  * SAFE=false drops the per-axis clamps and uses 32-bit offsets from an SGPR base when the
+//    host has proved both are safe (vk_api.hip: render_common).
+__device__ __forceinline__ int cvt_floor_i32(float u) {
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
+    return i;
+}
+__device__ __forceinline__ int med3_i32(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
+    constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
+    static_assert(PACKED || (!SKIP && SAFE), "linear layout: validation kernel only");
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
@@ -198,7 +229,9 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     float t0, t1;
     intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
     uint32_t n_iter = 0, n_samp = 0;
-    float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
+    // colour is accumulated as G = sum w*cos(phase); C = 0.5*A + 0.5*G at the end (sum w == A)
+    float Gr = 0.0f, Gg = 0.0f, Gb = 0.0f, A = 0.0f;
+    float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     if (!(t0 > t1)) {  // :91-93
         t0 = fmaxf(t0, 0.0f);  // :94
         const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
@@ -210,52 +243,77 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         const float sx = dir[0] * dt, sy = dir[1] * dt, sz = dir[2] * dt;  // :118
         const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
 
-        // empty-space skipping: steps that provably stay inside empty bricks
-        float k4 = 0.0f, k0 = 0.0f;
+        // per-ray constants of the skip bound (see below)
+        float idux = 0.f, iduy = 0.f, iduz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f, kpx = 0.f, kpy = 0.f, kpz = 0.f;
         if (SKIP) {
-            float m = fmaxf(fabsf(sx) * fnx, fmaxf(fabsf(sy) * fny, fabsf(sz) * fnz));
-            float inv_m = 1.0f / m;
-            k4 = (float)kBrick * inv_m;
-            k0 = fmaf(-((float)kBrick + 1.5f), inv_m, 1.0f);
+            idux = 1.0f / (fabsf(sx) * fnx); iduy = 1.0f / (fabsf(sy) * fny); iduz = 1.0f / (fabsf(sz) * fnz);
+            sgx = sx >= 0.0f ? -1.0f : 1.0f; sgy = sy >= 0.0f ? -1.0f : 1.0f; sgz = sz >= 0.0f ? -1.0f : 1.0f;
+            // margin 0.02 cells covers the rounding of the accumulated position (<= 1e-3 cells)
+            kpx = sx >= 0.0f ? -0.02f : -1.02f; kpy = sy >= 0.0f ? -0.02f : -1.02f; kpz = sz >= 0.0f ? -0.02f : -1.02f;
         }
 
         float t = t0;
         while (t < t1) {  // :101
-            float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
-            float flx = floorf(ux), fly = floorf(uy), flz = floorf(uz);
-            int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-            float tap[8];
-            if (VOL == VOL_PACKED_U8 || VOL == VOL_PACKED_F16) {
-                // cell index = clamp(i, -1, n-1) + 1  (identical taps to the clamp-to-edge sampler)
-                uint32_t cx = (uint32_t)(clampi(ix, -1, mx) + 1);
-                uint32_t cy = (uint32_t)(clampi(iy, -1, my) + 1);
-                uint32_t cz = (uint32_t)(clampi(iz, -1, mz) + 1);
-                uint32_t brick = ((cz >> 2) * V.nby + (cy >> 2)) * V.nbx + (cx >> 2);
-                if (SKIP) {
-                    uint32_t d = V.dist[brick];
-                    if (d != 0) {
-                        int k = max(1, (int)fmaf((float)d, k4, k0));
-                        do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
-                            px = px + sx; py = py + sy; pz = pz + sz;
-                            t = t + dt;
-                            n_iter++;
-                        } while (--k > 0 && t < t1);
-                        continue;
-                    }
-                }
-                size_t cell = (size_t)brick * kBrickCells + (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u));
-                if (VOL == VOL_PACKED_U8) {
-                    uint2 c = reinterpret_cast<const uint2 *>(V.data)[cell];
-                    tap[0] = (float)(c.x & 0xffu); tap[1] = (float)((c.x >> 8) & 0xffu);
-                    tap[2] = (float)((c.x >> 16) & 0xffu); tap[3] = (float)(c.x >> 24);
-                    tap[4] = (float)(c.y & 0xffu); tap[5] = (float)((c.y >> 8) & 0xffu);
-                    tap[6] = (float)((c.y >> 16) & 0xffu); tap[7] = (float)(c.y >> 24);
+            const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+            int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
+            const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+            float c00, c10, c01, c11;  // x-lerped corners
+            if (PACKED) {
+                if (SAFE) { ix = med3_i32(ix, -1, mx); iy = med3_i32(iy, -1, my); iz = med3_i32(iz, -1, mz); }
+                const int bx = ix >> 2, by = iy >> 2, bz = iz >> 2;
+                const char *cptr;
+                uint32_t d = 0;
+                if (SAFE) {
+                    int64_t off = (int64_t)bz * (int64_t)V.kz + (int64_t)(by * (int)V.ky + bx * (int)V.kx) +
+                                  (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
+                    off = off < 0 ? 0 : (off > (int64_t)V.max_off ? (int64_t)V.max_off : off);
+                    cptr = reinterpret_cast<const char *>(V.data) + off;
+                    if (SKIP) d = V.dist[off >> V.sh_x];
                 } else {
-                    uint4 c = reinterpret_cast<const uint4 *>(V.data)[cell];
-                    tap[0] = h2f(c.x & 0xffffu); tap[1] = h2f(c.x >> 16);
-                    tap[2] = h2f(c.y & 0xffffu); tap[3] = h2f(c.y >> 16);
-                    tap[4] = h2f(c.z & 0xffffu); tap[5] = h2f(c.z >> 16);
-                    tap[6] = h2f(c.w & 0xffffu); tap[7] = h2f(c.w >> 16);
+                    uint32_t off = (uint32_t)(bz * (int)V.kz + by * (int)V.ky + bx * (int)V.kx + (iz << V.sh_z) +
+                                              (iy << V.sh_y) + (ix << V.sh_x) + (int)V.c0);
+                    off = min(off, (uint32_t)V.max_off);  // memory-safety net; never binds for valid rays
+                    cptr = reinterpret_cast<const char *>(V.data) + off;
+                    if (SKIP) d = V.dist[off >> V.sh_x];
+                }
+                if (SKIP && d != 0) {
+                    // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
+                    // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
+                    // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margin.
+                    const float fd = (float)d;
+                    const float rx = fmaf(sgx, fx, fd + kpx) * idux;
+                    const float ry = fmaf(sgy, fy, fd + kpy) * iduy;
+                    const float rz = fmaf(sgz, fz, fd + kpz) * iduz;
+                    int k = (int)fminf(rx, fminf(ry, rz));  // NaN -> 0, saturating
+                    k = max(k, 0) + 1;  // the current sample is always skippable (its cell is empty)
+                    do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
+                        px = px + sx; py = py + sy; pz = pz + sz;
+                        t = t + dt;
+                        if (COUNT) n_iter++;
+                    } while (--k > 0 && t < t1);
+                    continue;
+                }
+                if (VOL == VOL_P8) {
+                    uint2 c = *reinterpret_cast<const uint2 *>(cptr);
+                    float t0_ = (float)(c.x & 0xffu), t1_ = (float)((c.x >> 8) & 0xffu);
+                    float t2_ = (float)((c.x >> 16) & 0xffu), t3_ = (float)(c.x >> 24);
+                    float t4_ = (float)(c.y & 0xffu), t5_ = (float)((c.y >> 8) & 0xffu);
+                    float t6_ = (float)((c.y >> 16) & 0xffu), t7_ = (float)(c.y >> 24);
+                    c00 = fmaf(fx, t1_ - t0_, t0_); c10 = fmaf(fx, t3_ - t2_, t2_);
+                    c01 = fmaf(fx, t5_ - t4_, t4_); c11 = fmaf(fx, t7_ - t6_, t6_);
+                } else if (VOL == VOL_P16) {
+                    union { uint4 u; half2_t h[4]; } c;
+                    c.u = *reinterpret_cast<const uint4 *>(cptr);
+                    // (tap, delta) pairs: delta = t1 - t0 is exact in f16 for u8 data -> v_fma_mix_f32
+                    c00 = fmaf(fx, (float)c.h[0].y, (float)c.h[0].x); c10 = fmaf(fx, (float)c.h[1].y, (float)c.h[1].x);
+                    c01 = fmaf(fx, (float)c.h[2].y, (float)c.h[2].x); c11 = fmaf(fx, (float)c.h[3].y, (float)c.h[3].x);
+                } else {
+                    union { uint4 u; half2_t h[4]; } c;
+                    c.u = *reinterpret_cast<const uint4 *>(cptr);
+                    float a0 = (float)c.h[0].x, a1 = (float)c.h[0].y, a2 = (float)c.h[1].x, a3 = (float)c.h[1].y;
+                    float a4 = (float)c.h[2].x, a5 = (float)c.h[2].y, a6 = (float)c.h[3].x, a7 = (float)c.h[3].y;
+                    c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
+                    c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
                 }
             } else {
                 int x0 = clampi(ix, 0, mx), x1 = clampi(ix + (ix < 0x7fffffff), 0, mx);
@@ -264,32 +322,41 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                 size_t sy_ = V.nx, sz_ = (size_t)V.nx * V.ny;
                 size_t r00 = y0 * sy_ + z0 * sz_, r10 = y1 * sy_ + z0 * sz_;
                 size_t r01 = y0 * sy_ + z1 * sz_, r11 = y1 * sy_ + z1 * sz_;
-                size_t id[8] = {r00 + x0, r00 + x1, r10 + x0, r10 + x1, r01 + x0, r01 + x1, r11 + x0, r11 + x1};
+                float tp[8];
                 if (VOL == VOL_LINEAR_U8) {
                     const uint8_t *v = reinterpret_cast<const uint8_t *>(V.data);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) tap[k] = (float)v[id[k]];
+                    tp[0] = (float)v[r00 + x0]; tp[1] = (float)v[r00 + x1]; tp[2] = (float)v[r10 + x0]; tp[3] = (float)v[r10 + x1];
+                    tp[4] = (float)v[r01 + x0]; tp[5] = (float)v[r01 + x1]; tp[6] = (float)v[r11 + x0]; tp[7] = (float)v[r11 + x1];
                 } else {
                     const uint16_t *v = reinterpret_cast<const uint16_t *>(V.data);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) tap[k] = h2f(v[id[k]]);
+                    tp[0] = h2f(v[r00 + x0]); tp[1] = h2f(v[r00 + x1]); tp[2] = h2f(v[r10 + x0]); tp[3] = h2f(v[r10 + x1]);
+                    tp[4] = h2f(v[r01 + x0]); tp[5] = h2f(v[r01 + x1]); tp[6] = h2f(v[r11 + x0]); tp[7] = h2f(v[r11 + x1]);
                 }
+                c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+                c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
             }
-            float r = trilerp(tap, ux - flx, uy - fly, uz - flz);
-            if (VOL == VOL_PACKED_U8 || VOL == VOL_LINEAR_U8) r = r * (1.0f / 255.0f);
-            float a = transfer_alpha(r);
-            float cr, cg, cb;
-            vertigo(a, cr, cg, cb);
-            n_iter++;
-            n_samp++;
-            float w = (1.0f - A) * a;  // :112-114
-            Cr = fmaf(w, cr, Cr); Cg = fmaf(w, cg, Cg); Cb = fmaf(w, cb, Cb);
+            float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
+            float r = fmaf(fz, c1 - c0, c0);
+            if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8) r = r * (1.0f / 255.0f);
+            const float a = transfer_alpha(r);
+            // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
+            constexpr double kk = 6.28318 / 6.283185307179586476925;
+            constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+            constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+            const float cr = __builtin_amdgcn_cosf(a * pc0);
+            const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+            const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+            if (COUNT) { n_iter++; n_samp++; }
+            const float w = (1.0f - A) * a;  // :112-114
+            Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
             A = A + w;
             if (A >= 0.95f) break;  // :115-117
             px = px + sx; py = py + sy; pz = pz + sz;  // :118
             t = t + dt;
         }
-        Cr = linear_to_srgb(Cr); Cg = linear_to_srgb(Cg); Cb = linear_to_srgb(Cb);  // :121-123
+        Cr = linear_to_srgb(fmaf(0.5f, Gr, 0.5f * A));  // :121-123
+        Cg = linear_to_srgb(fmaf(0.5f, Gg, 0.5f * A));
+        Cb = linear_to_srgb(fmaf(0.5f, Gb, 0.5f * A));
     }
     store_pixel<OUT>(L.out, pm.out_index, Cr, Cg, Cb, 1.0f);
     if (COUNT) {
@@ -392,11 +459,12 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
 }
 
 // ---- volume re-layout ------------------------------------------------------------------------
-// One thread per cell, cells enumerated in storage order (coalesced 8/16-byte stores).
-template <bool F16>
+// One thread per cell, cells enumerated in storage order (coalesced 8/16-byte stores).  Physical
+// brick B = (i >> 2) + 1 and in-brick w = i & 3 per axis, i = low-corner voxel index in [-1, n-1].
+template <int VOL>
 __global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict__ src, void *__restrict__ dst,
-                                                          uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx,
-                                                          uint32_t nby, uint64_t n_cells) {
+                                                          uint8_t *__restrict__ occ, uint32_t nx, uint32_t ny,
+                                                          uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_cells) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_cells) return;
     uint64_t brick = id >> 6;
@@ -404,77 +472,70 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict_
     uint32_t bx = (uint32_t)(brick % nbx);
     uint64_t rest = brick / nbx;
     uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
-    int ix = (int)(bx * 4 + (w & 3u)) - 1, iy = (int)(by * 4 + ((w >> 2) & 3u)) - 1, iz = (int)(bz * 4 + (w >> 4)) - 1;
+    int ix = ((int)bx - 1) * 4 + (int)(w & 3u), iy = ((int)by - 1) * 4 + (int)((w >> 2) & 3u), iz = ((int)bz - 1) * 4 + (int)(w >> 4);
     int mx = (int)nx - 1, my = (int)ny - 1, mz = (int)nz - 1;
     int xs[2] = {clampi(ix, 0, mx), clampi(ix + 1, 0, mx)};
     int ys[2] = {clampi(iy, 0, my), clampi(iy + 1, 0, my)};
     int zs[2] = {clampi(iz, 0, mz), clampi(iz + 1, 0, mz)};
-    if (!F16) {
-        const uint8_t *v = reinterpret_cast<const uint8_t *>(src);
-        uint32_t lo = 0, hi = 0;
+    uint32_t t[8];
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            size_t idx = (size_t)xs[b & 1] + (size_t)nx * ((size_t)ys[(b >> 1) & 1] + (size_t)ny * (size_t)zs[b >> 2]);
-            uint32_t t = v[idx];
-            if (b < 4) lo |= t << (8 * b); else hi |= t << (8 * (b - 4));
-        }
-        reinterpret_cast<uint2 *>(dst)[id] = make_uint2(lo, hi);
-    } else {
-        const uint16_t *v = reinterpret_cast<const uint16_t *>(src);
-        uint32_t o[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            size_t idx = (size_t)xs[b & 1] + (size_t)nx * ((size_t)ys[(b >> 1) & 1] + (size_t)ny * (size_t)zs[b >> 2]);
-            o[b >> 1] |= (uint32_t)v[idx] << (16 * (b & 1));
-        }
-        reinterpret_cast<uint4 *>(dst)[id] = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int b = 0; b < 8; b++) {
+        size_t idx = (size_t)xs[b & 1] + (size_t)nx * ((size_t)ys[(b >> 1) & 1] + (size_t)ny * (size_t)zs[b >> 2]);
+        t[b] = (VOL == VOL_PF16) ? (uint32_t)reinterpret_cast<const uint16_t *>(src)[idx]
+                                 : (uint32_t)reinterpret_cast<const uint8_t *>(src)[idx];
     }
-}
-
-// occ[brick] = 0 if any tap of any cell of the brick is above the transfer function's zero
-// threshold (u8 > 25: 25/255 < 0.1 <= 26/255; f16 > 0.1f or NaN), else 255.
-template <bool F16>
-__global__ __launch_bounds__(64) void brick_occupancy_kernel(const void *__restrict__ cells, uint8_t *__restrict__ occ,
-                                                             uint64_t n_bricks) {
-    uint64_t brick = blockIdx.x;  // one wave per brick, one lane per cell
-    if (brick >= n_bricks) return;
-    uint64_t id = brick * 64 + threadIdx.x;
+    // occ = 0 if any tap is above the transfer function's zero threshold (u8 > 25: 25/255 < 0.1 <=
+    // 26/255; f16 > 0.1f or NaN), else 255 ("no contributing cell seen yet")
     bool nonempty = false;
-    if (!F16) {
-        uint2 c = reinterpret_cast<const uint2 *>(cells)[id];
 #pragma unroll
-        for (int b = 0; b < 4; b++) nonempty |= ((c.x >> (8 * b)) & 0xffu) > 25u || ((c.y >> (8 * b)) & 0xffu) > 25u;
-    } else {
-        uint4 c = reinterpret_cast<const uint4 *>(cells)[id];
-        uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    for (int b = 0; b < 8; b++) nonempty |= (VOL == VOL_PF16) ? !(h2f(t[b]) <= 0.1f) : (t[b] > 25u);
+    occ[id] = nonempty ? 0 : 255;
+    if (VOL == VOL_P8) {
+        uint32_t lo = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+        uint32_t hi = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
+        reinterpret_cast<uint2 *>(dst)[id] = make_uint2(lo, hi);
+    } else if (VOL == VOL_P16) {
+        union { uint4 u; _Float16 h[8]; } c;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            float a = h2f(w[b] & 0xffffu), bb = h2f(w[b] >> 16);
-            nonempty |= !(a <= 0.1f) || !(bb <= 0.1f);
+        for (int k = 0; k < 4; k++) {
+            c.h[2 * k] = (_Float16)(float)t[2 * k];                                  // tap (dx = 0)
+            c.h[2 * k + 1] = (_Float16)((float)t[2 * k + 1] - (float)t[2 * k]);      // delta, |.| <= 255: exact
         }
+        reinterpret_cast<uint4 *>(dst)[id] = c.u;
+    } else {
+        reinterpret_cast<uint4 *>(dst)[id] = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
     }
-    unsigned long long any = __ballot(nonempty);
-    if (threadIdx.x == 0) occ[brick] = any ? 0 : 255;
 }
 
-// One separable pass of the Chebyshev (L-infinity) distance transform on the brick grid:
-// out(b) = min_j max(in(b + j*axis), |j|), |j| <= kDistRadius.  Outside the grid counts as empty.
+// One separable pass of the Chebyshev (L-infinity) distance transform over the cells:
+// out(c) = min_j max(in(c + j*axis), |j|), |j| <= kDistRadius.  Outside the grid counts as empty.
+// Cells are addressed in their bricked storage order.
+__device__ __forceinline__ uint64_t cell_index(uint32_t x, uint32_t y, uint32_t z, uint32_t nbx, uint32_t nby) {
+    uint64_t brick = ((uint64_t)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
+    return brick * 64 + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
+}
+
 __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                         uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int last) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t n = (uint64_t)nbx * nby * nbz;
+    uint64_t n = (uint64_t)nbx * nby * nbz * 64;
     if (id >= n) return;
-    uint32_t bx = (uint32_t)(id % nbx);
-    uint64_t rest = id / nbx;
+    uint64_t brick = id >> 6;
+    uint32_t w = (uint32_t)(id & 63u);
+    uint32_t bx = (uint32_t)(brick % nbx);
+    uint64_t rest = brick / nbx;
     uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
-    int c = axis == 0 ? (int)bx : (axis == 1 ? (int)by : (int)bz);
-    int dim = axis == 0 ? (int)nbx : (axis == 1 ? (int)nby : (int)nbz);
-    int64_t stride = axis == 0 ? 1 : (axis == 1 ? (int64_t)nbx : (int64_t)nbx * nby);
-    int best = 255;
-    int jlo = max(-kDistRadius, -c), jhi = min(kDistRadius, dim - 1 - c);
+    uint32_t c[3] = {bx * 4 + (w & 3u), by * 4 + ((w >> 2) & 3u), bz * 4 + (w >> 4)};
+    const int dim = (int)(axis == 0 ? nbx : (axis == 1 ? nby : nbz)) * 4;
+    const int c0 = (int)c[axis];
+    int best = in[id];
+    const int jlo = max(-kDistRadius, -c0), jhi = min(kDistRadius, dim - 1 - c0);
     for (int j = jlo; j <= jhi; j++) {
-        int v = in[(int64_t)id + j * stride];
-        int aj = j < 0 ? -j : j;
+        const int aj = j < 0 ? -j : j;
+        if (aj >= best) continue;  // cannot improve
+        uint32_t q[3] = {c[0], c[1], c[2]};
+        q[axis] = (uint32_t)(c0 + j);
+        const int v = in[cell_index(q[0], q[1], q[2], nbx, nby)];
         best = min(best, max(v, aj));
     }
     if (last) best = min(best, kDistRadius + 1);
