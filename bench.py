@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: Mray-steps/s of the volume raycast on the
+256^3 uint8 bonsai (stand-in) at 1920x1080, dt_scale 0.5 ("512 steps/ray"), plus the achieved
+fraction of the HBM-read roofline (BASELINE.json / SURVEY.md 8d, config C2).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame: one pass of the raycast over every pixel.  At N > 1 the SAME frame is
+partitioned: 64x64-pixel tiles interleaved over ranks, each rank marches its tiles, one RCCL
+gather per frame brings the tile pixels to rank 0 over xGMI and rank 0 un-tiles them
+(scaling: strong; frames are pipelined so the gather of frame k overlaps the march of k+1).
+
+value   = S_ref * K / t  [Mray-steps/s]: S_ref = loop iterations the reference shader executes for
+          this frame (with its alpha >= 0.95 early-out), counted by the kernel itself in an untimed
+          counting launch and equal to the oracle's count (tests).  Volume resident in HBM.
+roofline: algorithmic bytes of one launch = S_sampled * 8 B (8 trilinear u8 taps per tap-fetching
+          step) + W*H * 8 B (rgba16f store), over the launch's mean duration from HIP events on
+          the launch stream, against 8 TB/s.  See DESIGN.md "Measurement".
+cpu_baseline: the C oracle (oracle/, a port of the reference WGSL -- the reference's wgpu/Vulkan
+          path cannot run: no Rust, no Vulkan ICD) timed on the host cores for the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, N_VOL, DT_SCALE = 1920, 1080, 256, 0.5
+TILE = 64
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
+B_STEP, B_RAY = 8, 8       # 8 u8 taps per step; rgba16f per ray
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
+    ap.add_argument("--layout", default="pairs", choices=["pairs", "packed"], help="cell format of the u8 volume")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
+    ap.add_argument("--force-dist", action="store_true", help="use the partition + gather path even at N = 1 (self-test)")
+    return ap.parse_args()
+
+
+def time_launches(ctx, pipe, iters, warm=5):
+    """Mean duration of one launch from HIP events on the launch stream."""
+    for _ in range(warm):
+        pipe.record(ctx)
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(iters):
+        pipe.record(ctx)
+    ctx.timer_end()
+    return ctx.timer_elapsed_ms() / iters
+
+
+def count_steps(ctx, V, flags):
+    ctx.reset_step_counts()
+    V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags | V.RENDER_COUNT).record(ctx)
+    return ctx.step_counts()
+
+
+def effective_cpus() -> int:
+    """Host threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(blob):
+    """The oracle (CPU port of the reference shader) on the same C2 frame, all host threads."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    O.build()
+    vol = O.volume_standin_u8(N_VOL)
+    threads = effective_cpus()
+    O.render(blob, vol, W, H // 8, dt_scale=DT_SCALE, threads=threads, want_counts=False)  # page in
+    times, s_ref = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, steps, _ = O.render(blob, vol, W, H, dt_scale=DT_SCALE, threads=threads)
+        times.append(time.perf_counter() - t0)
+        s_ref = int(steps.sum())
+    t_all = float(np.median(times))
+    # one thread, every 8th row band (scaled by its own step count)
+    t0 = time.perf_counter()
+    _, st1, _ = O.render(blob, vol, W, H, dt_scale=DT_SCALE, threads=1, tile=(0, H // 2 - 32, W, 64))
+    t_one = time.perf_counter() - t0
+    return {
+        "value": s_ref / t_all / 1e6, "unit": "Mray-steps/s", "cores": threads, "kind": "port",
+        "sample": f"3 full C2 frames (median), OpenMP dynamic over rows, {threads} threads; oracle/vokselis_oracle.c",
+        "one_thread_value": int(st1.sum()) / t_one / 1e6, "one_thread_sample": "rows 508..571 of the C2 frame, 1 thread",
+        "s_ref": s_ref,
+    }, s_ref
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as G
+
+    if rank == 0:
+        G.build_hip()
+    if world > 1:
+        dist.barrier()
+    import vokselis_amd as V
+    from vokselis_amd.dist import TileParallelRenderer
+
+    layout = V.LAYOUT_PACKED_PAIRS if args.layout == "pairs" else V.LAYOUT_PACKED
+    flags = V.RENDER_NO_SKIP if args.no_skip else 0
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)  # examples/bonsai/main.rs:68-74
+        blob = cam.get_proj_view_matrix()
+        ctx = V.Context(W, H, cam, device=local_rank, backbuffer=(W, H), out_format=V.OUT_RGBA16F, stream=stream.cuda_stream)
+        info = ctx.get_info()
+        t0 = time.perf_counter()
+        V.VolumeTexture.generate_standin(ctx, (N_VOL,) * 3, layout=layout)
+        ctx.sync()
+        t_volume = time.perf_counter() - t0
+        ctx.update()
+        pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
+
+        # untimed counting launch: the units one frame processes
+        s_ref, s_sampled = count_steps(ctx, V, flags)
+
+        if not use_dist:
+            def step(_k):
+                pipe.record(ctx)
+
+            def drain():
+                pass
+        else:
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=TILE, root=0)
+            step, drain = tpr.submit, tpr.flush
+
+        for k in range(args.warmup):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.timer_begin()
+        t_start = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        drain()
+        ctx.timer_end()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        ev_ms = ctx.timer_elapsed_ms() / args.steps
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        out = None
+        if rank == 0:
+            n_px = W * H
+            ms_per_step = elapsed / args.steps * 1e3
+            alg_bytes = s_sampled * B_STEP + n_px * B_RAY
+            achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+            out = {
+                "metric": "Mray-steps/s on 256^3 uint8 @1920x1080; achieved % HBM-read roofline",
+                "value": s_ref * args.steps / elapsed / 1e6,
+                "unit": "Mray-steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {
+                    "workload": "C2: bonsai stand-in 256^3 uint8 (device-generated, seed 0x5EED0001), 1920x1080, "
+                                "bonsai camera (1,.5,1,(.5,.5,.5)), NAIVE_TRILINEAR, dt_scale 0.5 (<=513 steps/ray), rgba16f out",
+                    "layout": "4^3-bricked cells, " + ("4 (tap,delta) f16 pairs / 16 B" if args.layout == "pairs" else "8 u8 taps / 8 B"),
+                    "skip": not args.no_skip,
+                    "partition": "single launch" if world == 1 else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0",
+                    "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
+                },
+                "roofline": {
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "vk::raymarch_naive_kernel", "launch_ms": ev_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                    # the same launch priced at the reference's own step count (every iteration of
+                    # the reference loop reads 8 taps; skipped iterations are provably alpha == 0)
+                    "achieved_at_reference_steps": (s_ref * B_STEP + n_px * B_RAY) / (ev_ms * 1e-3) / 1e9,
+                    "frac_at_reference_steps": (s_ref * B_STEP + n_px * B_RAY) / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                },
+                "device": info["device_name"], "volume_setup_s": t_volume,
+            }
+            prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(prof) and world == 1 and not args.no_skip and args.layout == "pairs":
+                try:
+                    pj = json.load(open(prof))
+                    out["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = pj.get("source", "profiles/r01_pmc_traffic.json")
+                except Exception:
+                    pass
+
+        # untimed side measurements (rank 0, N = 1): the tap-fetching kernel without skipping, on
+        # the stand-in and on fog -- the configuration in which every iteration reads its 8 taps
+        if world == 1 and not args.no_extras:
+            extras = {}
+            it = 50
+            p_ns = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_NO_SKIP)
+            p_sk = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=0)
+            for name, mk in (("standin", None), ("fog", lambda: V.VolumeTexture.generate_fog(ctx, (N_VOL,) * 3, layout=layout))):
+                if mk is not None:
+                    mk()
+                for mode, p, fl in (("noskip", p_ns, V.RENDER_NO_SKIP), ("skip", p_sk, 0)):
+                    sr, ss = count_steps(ctx, V, fl)
+                    ms = time_launches(ctx, p, it)
+                    gb = (ss * B_STEP + W * H * B_RAY) / (ms * 1e-3) / 1e9
+                    extras[f"{name}_{mode}"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
+                                               "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+            out["extras"] = extras
+
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cb, s_cpu = cpu_baseline(blob)
+            out["cpu_baseline"] = cb
+            out["cpu_baseline"]["s_ref_matches_gpu"] = (s_cpu == s_ref)
+        ctx.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON line is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

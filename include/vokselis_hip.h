@@ -81,10 +81,14 @@ int vk_volume_upload(vk_ctx *ctx, const void *host, const void *host2, uint32_t 
 /* Same, but the dense source already lives in device memory of this GPU (large synthetic volumes). */
 int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint32_t nx, uint32_t ny,
                             uint32_t nz, int format, int layout);
-/* Deterministic fog volume generated on the device (bit-identical to oracle vo_volume_fog_*):
- * kind 0 = u8 in [lo, lo+span), kind 1 = f16 bit patterns 0x2D1F + h % 656. */
-int vk_volume_generate_fog(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
-                           uint32_t lo, uint32_t span, int layout);
+/* Deterministic synthetic volume generated on the device, integer arithmetic only (bit-identical
+ * to the oracle's vo_volume_* and to vokselis_amd/volumes.py).  The reference embeds its volume
+ * with include_bytes! (volume_texture.rs:33) and that file is absent from the checkout, so the
+ * bench and the tests use these.  FOG: u8 in [lo, lo+span) / f16 bit patterns 0x2D1F + h % 656.
+ * BONSAI_STANDIN: pot / trunk / canopy / speckled air, u8. */
+enum vk_generator { VK_GEN_FOG = 0, VK_GEN_BONSAI_STANDIN = 1 };
+int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
+                       uint32_t lo, uint32_t span, int layout);
 int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes);
 
 /* GlobalUniformBinding::update, src/context/global_ubo.rs:47-49 (48-byte Uniform, :52-65). */

@@ -136,3 +136,14 @@ def test_untile_reference_roundtrip():
             tile = frame[y0:y0 + ts, x0:x0 + ts]
             gathered[r, j, :tile.shape[0], :tile.shape[1]] = tile
     assert (D.untile_reference(gathered, w, h, ts) == frame).all()
+
+
+def test_host_volume_generators_match_oracle(O):
+    from vokselis_amd import volumes
+
+    for dims in (32, (40, 24, 56)):
+        assert (volumes.bonsai_standin(dims, seed=9) == O.volume_standin_u8(dims, seed=9)).all()
+        assert (volumes.fog_u8(dims, seed=9) == O.volume_fog_u8(dims, seed=9)).all()
+        assert (volumes.fog_f16(dims, seed=9).view(np.uint16) == O.volume_fog_f16(dims, seed=9).view(np.uint16)).all()
+    v = O.volume_standin_u8(128)
+    assert 0.65 <= (v <= 25).mean() <= 0.9 and v.max() >= 232  # >= 65 % exactly transparent

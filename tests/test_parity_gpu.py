@@ -204,6 +204,17 @@ def test_device_fog_generator_is_bit_identical(V, O):
             assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL and (ctx.read_steps() == rsteps).all()
         finally:
             ctx.close()
+    # the bonsai stand-in made on the device renders bit-identically to the host-uploaded one
+    host = O.volume_standin_u8((72, 40, 56), seed=3)
+    a, sa, _ = gpu_render(V, cam, host, 80, 80, dt=0.5)
+    ctx = V.Context(80, 80, backbuffer=(80, 80), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture.generate_standin(ctx, (72, 40, 56), seed=3)
+        ctx.set_camera_blob(cam)
+        V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)
+        assert (ctx.read_backbuffer() == a).all() and (ctx.read_steps() == sa).all()
+    finally:
+        ctx.close()
 
 
 def test_cameras_dims_and_dt(V, O):

@@ -9,15 +9,16 @@ Only the raycast hot path and the host surface that drives it live here (SURVEY.
   dist       tile-parallel multi-GPU frame (one process per GPU, RCCL gather over xGMI)
 """
 from . import _native as native
+from . import volumes
 from ._native import (FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR, LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, RENDER_SAFE,
-                      MODE_COMPUTE_NEAREST, MODE_NAIVE_TRILINEAR, OUT_RGBA16F, OUT_RGBA32F, RENDER_COUNT,
+                      GEN_BONSAI_STANDIN, GEN_FOG, MODE_COMPUTE_NEAREST, MODE_NAIVE_TRILINEAR, OUT_RGBA16F, OUT_RGBA32F, RENDER_COUNT,
                       RENDER_NO_SKIP, VokselisError)
 from .camera import Camera
 from .context import (Context, Demo, FrameCounter, HdrBackBuffer, ImageDimentions, RaycastPipeline, Uniform,
                       VolumeTexture, dispatch_optimal, partition_slots, run_headless)
 
 __all__ = [
-    "native", "Camera", "Context", "Demo", "FrameCounter", "HdrBackBuffer", "ImageDimentions", "RaycastPipeline",
+    "native", "volumes", "GEN_BONSAI_STANDIN", "GEN_FOG", "Camera", "Context", "Demo", "FrameCounter", "HdrBackBuffer", "ImageDimentions", "RaycastPipeline",
     "Uniform", "VolumeTexture", "dispatch_optimal", "partition_slots", "run_headless", "VokselisError",
     "FMT_R8_UNORM", "FMT_R16_FLOAT", "FMT_RGBA16F_PAIR", "LAYOUT_AUTO", "LAYOUT_LINEAR", "LAYOUT_PACKED", "LAYOUT_PACKED_PAIRS", "RENDER_SAFE",
     "MODE_COMPUTE_NEAREST", "MODE_NAIVE_TRILINEAR", "OUT_RGBA16F", "OUT_RGBA32F", "RENDER_COUNT", "RENDER_NO_SKIP",

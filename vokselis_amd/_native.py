@@ -16,6 +16,7 @@ MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
 LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS = 0, 1, 2, 3
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE = 1, 2, 4
+GEN_FOG, GEN_BONSAI_STANDIN = 0, 1
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
 _u32, _i32, _f32, _vp, _sz = C.c_uint32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
@@ -29,7 +30,7 @@ SYMBOLS = {
     "vk_last_error": (C.c_char_p, [_vp]),
     "vk_volume_upload": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
     "vk_volume_upload_device": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
-    "vk_volume_generate_fog": (C.c_int, [_vp, _u32, _u32, _u32, C.c_int, _u32, _u32, _u32, C.c_int]),
+    "vk_volume_generate": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, C.c_int, _u32, _u32, _u32, C.c_int]),
     "vk_volume_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
     "vk_set_uniform": (C.c_int, [_vp, _vp]),
     "vk_set_camera": (C.c_int, [_vp, _vp]),

@@ -256,13 +256,23 @@ class VolumeTexture:
         return cls(ctx, raw.reshape(nz, ny, nx), layout=layout)
 
     @classmethod
-    def generate_fog(cls, ctx: Context, dims, fmt=N.FMT_R8_UNORM, seed=0x5EED0002, lo=20, span=12,
-                     layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
+    def generate(cls, ctx: Context, kind: int, dims, fmt=N.FMT_R8_UNORM, seed=0x5EED0001, lo=20, span=12,
+                 layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
+        """Deterministic synthetic volume made on the device (GEN_FOG / GEN_BONSAI_STANDIN)."""
         nx, ny, nz = dims
-        N.check(ctx.handle, N.lib().vk_volume_generate_fog(ctx.handle, nx, ny, nz, fmt, seed, lo, span, layout))
+        N.check(ctx.handle, N.lib().vk_volume_generate(ctx.handle, kind, nx, ny, nz, fmt, seed, lo, span, layout))
         self = cls.__new__(cls)
         self.dims, self.format = (nx, ny, nz), fmt
         return self
+
+    @classmethod
+    def generate_fog(cls, ctx: Context, dims, fmt=N.FMT_R8_UNORM, seed=0x5EED0002, lo=20, span=12,
+                     layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
+        return cls.generate(ctx, N.GEN_FOG, dims, fmt, seed, lo, span, layout)
+
+    @classmethod
+    def generate_standin(cls, ctx: Context, dims=(256, 256, 256), seed=0x5EED0001, layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
+        return cls.generate(ctx, N.GEN_BONSAI_STANDIN, dims, N.FMT_R8_UNORM, seed, 0, 1, layout)
 
 
 class RaycastPipeline:

@@ -287,13 +287,15 @@ int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint
     return build_from_dense(ctx, dev, dev2, false, nx, ny, nz, format, layout);
 }
 
-int vk_volume_generate_fog(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed, uint32_t lo,
-                           uint32_t span, int layout) {
+int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
+                       uint32_t lo, uint32_t span, int layout) {
     int dummy = 0;
     int rc = check_volume_args(ctx, &dummy, nullptr, nx, ny, nz, format, layout);
     if (rc) return rc;
-    if (format == VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_UNSUPPORTED, "fog generator makes scalar volumes");
-    if (format == VK_FMT_R8_UNORM && (span == 0 || lo + span > 256)) return fail(ctx, VK_ERR_INVALID, "fog range outside u8");
+    if (kind != VK_GEN_FOG && kind != VK_GEN_BONSAI_STANDIN) return fail(ctx, VK_ERR_INVALID, "unknown generator kind");
+    if (format == VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_UNSUPPORTED, "generators make scalar volumes");
+    if (kind == VK_GEN_BONSAI_STANDIN && format != VK_FMT_R8_UNORM) return fail(ctx, VK_ERR_UNSUPPORTED, "the bonsai stand-in is a u8 volume");
+    if (kind == VK_GEN_FOG && format == VK_FMT_R8_UNORM && (span == 0 || lo + span > 256)) return fail(ctx, VK_ERR_INVALID, "fog range outside u8");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_vox = (size_t)nx * ny * nz;
     const size_t bpv = format == VK_FMT_R8_UNORM ? 1 : 2;
@@ -301,12 +303,14 @@ int vk_volume_generate_fog(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, i
     HIP_TRY(ctx, hipMalloc(&d, n_vox * bpv));
     const uint64_t blocks = (n_vox + 255) / 256;
     if (blocks >= (1ull << 31)) { (void)hipFree(d); return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large"); }
-    if (format == VK_FMT_R16_FLOAT)
-        hipLaunchKernelGGL(fog_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+    if (kind == VK_GEN_BONSAI_STANDIN)
+        hipLaunchKernelGGL(generate_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+    else if (format == VK_FMT_R16_FLOAT)
+        hipLaunchKernelGGL(generate_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
     else
-        hipLaunchKernelGGL(fog_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+        hipLaunchKernelGGL(generate_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, VK_ERR_HIP, std::string("fog launch: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, VK_ERR_HIP, std::string("generator launch: ") + hipGetErrorString(e)); }
     return build_from_dense(ctx, d, nullptr, true, nx, ny, nz, format, layout);
 }
 

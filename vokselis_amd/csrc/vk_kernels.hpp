@@ -551,19 +551,74 @@ __device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z, ui
     return lowbias32(seed ^ (x * 0x9E3779B1U + y * 0x85EBCA77U + z * 0xC2B2AE3DU));
 }
 
-// Deterministic fog (bit-identical to vo_volume_fog_u8 / vo_volume_fog_f16)
-template <bool F16>
-__global__ __launch_bounds__(256) void fog_kernel(void *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
-                                                  uint32_t seed, uint32_t lo, uint32_t span) {
+// Deterministic synthetic volumes, integer arithmetic only (bit-identical to the oracle's
+// vo_volume_fog_u8 / vo_volume_fog_f16 / vo_volume_standin_u8 and to vokselis_amd/volumes.py).
+__device__ __forceinline__ uint32_t vnoise(uint32_t X, uint32_t Y, uint32_t Z, uint32_t sh, uint32_t seed) {
+    const uint32_t m = (1u << sh) - 1, S = 1u << sh;
+    const uint32_t cx = X >> sh, cy = Y >> sh, cz = Z >> sh;
+    const uint32_t fx = X & m, fy = Y & m, fz = Z & m;
+    uint64_t acc = 0;
+#pragma unroll
+    for (uint32_t dz = 0; dz < 2; dz++)
+#pragma unroll
+        for (uint32_t dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (uint32_t dx = 0; dx < 2; dx++) {
+                uint64_t w = (uint64_t)(dx ? fx : S - fx) * (dy ? fy : S - fy) * (dz ? fz : S - fz);
+                acc += w * (hash3(cx + dx, cy + dy, cz + dz, seed) >> 24);
+            }
+    return (uint32_t)(acc >> (3 * sh));
+}
+
+// "bonsai stand-in": dense pot (>= 232), mid-density bent trunk, smooth noise-thresholded canopy,
+// air = white noise 0..20 (exactly transparent) with 0.2 % speckle 26..41.  SURVEY 8(d) C1.
+__device__ __forceinline__ uint32_t standin_voxel(uint32_t x, uint32_t y, uint32_t z, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed) {
+    const int32_t X = (int32_t)(((2 * (uint64_t)x + 1) * 2048) / nx);
+    const int32_t Y = (int32_t)(((2 * (uint64_t)y + 1) * 2048) / ny);
+    const int32_t Z = (int32_t)(((2 * (uint64_t)z + 1) * 2048) / nz);
+    const uint32_t n_lo = vnoise((uint32_t)X, (uint32_t)Y, (uint32_t)Z, 9, seed ^ 0x1111u);
+    const uint32_t n_hi = vnoise((uint32_t)X, (uint32_t)Y, (uint32_t)Z, 7, seed ^ 0x2222u);
+    {
+        int64_t dx = X - 2048, dy = Y - 600, dz = Z - 2048;
+        if (dx * dx + 7 * dy * dy + dz * dz < 1400 * 1400) return 232 + (n_hi >> 4);
+    }
+    if (Y >= 900 && Y < 2600) {
+        int32_t h = Y - 900;
+        int64_t cx = 2048 + ((int64_t)h * h) / 8000, cz = 2048 - h / 6, rr = 230 - h / 12;
+        int64_t dx = X - cx, dz = Z - cz;
+        if (dx * dx + dz * dz < rr * rr) return 110 + (n_hi >> 2);
+    }
+    {
+        int64_t dx = X - 2150, dy = Y - 2850, dz = Z - 1950;
+        int64_t q = (dx * dx * 256) / (1750 * 1750) + (dy * dy * 256) / (1050 * 1050) + (dz * dz * 256) / (1750 * 1750);
+        if (q < 256) {
+            int32_t f = (int32_t)((2 * n_lo + n_hi) / 3);
+            int32_t d = f - (int32_t)(q / 3) - 52;
+            if (d > 0) { int32_t v = 28 + 2 * d; return (uint32_t)(v > 225 ? 225 : v); }
+        }
+    }
+    const uint32_t h = hash3(x, y, z, seed ^ 0x3333u);
+    if ((h & 0x1ffu) == 0) return 26 + ((h >> 9) & 15);
+    return (h >> 16) % 21;
+}
+
+// kind 0: fog u8 in [lo, lo+span); 1: fog f16 bit patterns 0x2D1F + h % 656; 2: bonsai stand-in u8
+template <int KIND>
+__global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
+                                                       uint32_t seed, uint32_t lo, uint32_t span) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t n = (uint64_t)nx * ny * nz;
     if (id >= n) return;
     uint32_t x = (uint32_t)(id % nx);
     uint64_t rest = id / nx;
     uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
-    uint32_t h = hash3(x, y, z, seed) >> 8;
-    if (F16) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(0x2D1Fu + h % 656u);
-    else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(lo + h % span);
+    if (KIND == 2) {
+        reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)standin_voxel(x, y, z, nx, ny, nz, seed);
+    } else {
+        uint32_t h = hash3(x, y, z, seed) >> 8;
+        if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(0x2D1Fu + h % 656u);
+        else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(lo + h % span);
+    }
 }
 
 template <int OUT>
