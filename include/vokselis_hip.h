@@ -114,12 +114,17 @@ int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t ti
 
 /* Multi-GPU partition of one frame: the backbuffer-sized frame is cut into tile_size^2 tiles
  * (row-major; the reference's TILE_SIZE scheme, examples/xor/main.rs:12,77-95); this call
- * renders the tiles t with t % nranks == rank into `compact_out` (device memory,
- * [n_slots][tile_size][tile_size] pixels of the backbuffer's format, slot j <-> tile rank+j*nranks).
+ * renders the tiles at positions q = rank + j*nranks of the heaviest-first order (vk_partition_order)
+ * into `compact_out` (device memory, [n_slots][tile_size][tile_size] pixels of the backbuffer's
+ * format, slot j <-> position rank + j*nranks).
  * vk_partition_slots gives n_slots (identical on every rank, for a fixed-size gather). */
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots);
 int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                         float dt_scale, uint32_t flags, void *compact_out);
+/* The partition deals tiles heaviest-first (a launch/balance heuristic derived from the camera):
+ * position q of the order belongs to rank q % nranks, slot q / nranks.  order_out[q] = row-major
+ * tile id; identical on every rank for identical camera, volume dims and backbuffer size. */
+int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *order_out, uint32_t n_tiles);
 /* Root side: scatter the gathered [nranks][n_slots][ts][ts] pixels into the backbuffer. */
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks);
 
@@ -131,6 +136,10 @@ int vk_readback(vk_ctx *ctx, void *dst, size_t row_pitch_bytes);
  * reference would execute (S_ref) and iterations in which taps were fetched (S_sampled). */
 int vk_step_counts(vk_ctx *ctx, uint64_t *s_ref, uint64_t *s_sampled);
 int vk_step_counts_reset(vk_ctx *ctx);
+/* SIMT execution census of the VK_RENDER_COUNT launches since the last reset (NAIVE mode):
+ * out[0] wave-level march-loop iterations, out[1] wave-level skipped-step iterations,
+ * out[2] wave-level sample executions, out[3] per-lane march-loop iterations (lookups). */
+int vk_simt_census(vk_ctx *ctx, uint64_t out[4]);
 /* Per-pixel executed loop iterations of the last VK_RENDER_COUNT launch ([height][width] u32). */
 int vk_readback_steps(vk_ctx *ctx, uint32_t *dst);
 

@@ -128,14 +128,15 @@ def test_untile_reference_roundtrip():
     w, h, ts, world = 100, 60, 16, 3
     frame = rng.random((h, w, 4)).astype(np.float32)
     slots = D.n_slots(w, h, ts, world)
-    gathered = np.zeros((world, slots, ts, ts, 4), np.float32)
-    tx, _ = D.tiles_xy(w, h, ts)
-    for r in range(world):
-        for j, t in enumerate(D.local_tiles(w, h, ts, r, world)):
-            y0, x0 = (t // tx) * ts, (t % tx) * ts
-            tile = frame[y0:y0 + ts, x0:x0 + ts]
-            gathered[r, j, :tile.shape[0], :tile.shape[1]] = tile
-    assert (D.untile_reference(gathered, w, h, ts) == frame).all()
+    tx, ty = D.tiles_xy(w, h, ts)
+    for order in (None, rng.permutation(tx * ty)):  # identity and an arbitrary (heaviest-first-like) order
+        gathered = np.zeros((world, slots, ts, ts, 4), np.float32)
+        for r in range(world):
+            for j, t in enumerate(D.local_tiles(w, h, ts, r, world, order)):
+                y0, x0 = (t // tx) * ts, (t % tx) * ts
+                tile = frame[y0:y0 + ts, x0:x0 + ts]
+                gathered[r, j, :tile.shape[0], :tile.shape[1]] = tile
+        assert (D.untile_reference(gathered, w, h, ts, order) == frame).all()
 
 
 def test_host_volume_generators_match_oracle(O):

@@ -167,7 +167,9 @@ def test_partition_untile_equals_frame(V, O):
             for r in range(world):
                 pipe.record_partition(ctx, ts, r, world, gathered[r].data_ptr())
             ctx.sync()
-            host = D.untile_reference(gathered.cpu().numpy(), W, H, ts)
+            order = ctx.partition_order(ts)
+            assert sorted(order.tolist()) == list(range(len(order)))  # a permutation of the tiles
+            host = D.untile_reference(gathered.cpu().numpy(), W, H, ts, order)
             assert np.abs(host - ref).max() <= TOL
             V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world))
             img = ctx.read_backbuffer()

@@ -196,10 +196,23 @@ class Context:
         buf[:, : dims.unpadded_bytes_per_row] = rgba8.reshape(dims.height, -1)
         return buf.tobytes(), dims
 
+    def partition_order(self, tile_size: int, mode: int = N.MODE_NAIVE_TRILINEAR) -> np.ndarray:
+        """Heaviest-first tile order of the frame partition (position -> row-major tile id)."""
+        bb = self.render_backbuffer
+        n = ((bb.width + tile_size - 1) // tile_size) * ((bb.height + tile_size - 1) // tile_size)
+        out = np.empty(n, np.uint32)
+        N.check(self._h, N.lib().vk_partition_order(self._h, mode, tile_size, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out
+
     def step_counts(self):
         a, b = C.c_uint64(), C.c_uint64()
         N.check(self._h, N.lib().vk_step_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def simt_census(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        N.check(self._h, N.lib().vk_simt_census(self._h, out))
+        return {"wave_loop_iters": out[0], "wave_skip_iters": out[1], "wave_sample_execs": out[2], "lane_loop_iters": out[3]}
 
     def reset_step_counts(self):
         N.check(self._h, N.lib().vk_step_counts_reset(self._h))

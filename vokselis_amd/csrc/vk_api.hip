@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace vk;
 
@@ -42,6 +43,12 @@ struct vk_ctx {
     int out_format = VK_OUT_RGBA32F;
     uint32_t *steps = nullptr;
     unsigned long long *counters = nullptr;
+
+    // heaviest-first tile order (launch-order heuristic; see tile_order_update)
+    std::vector<uint32_t> order, order_pos;
+    std::vector<unsigned char> order_key;
+    uint32_t *d_order = nullptr, *d_order_pos = nullptr;
+    size_t d_order_cap = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_open = false, timing_done = false;
@@ -105,8 +112,8 @@ int vk_ctx_create(int device_ordinal, vk_ctx **out) {
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc(&ctx->counters, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMemset(ctx->counters, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipMalloc(&ctx->counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(counters)");
     *out = ctx;
     return VK_OK;
 }
@@ -129,6 +136,8 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
     if (ctx->steps) (void)hipFree(ctx->steps);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -406,6 +415,86 @@ static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     else { if (safe) launch_naive<VOL, false, true>(ctx, L, V, grid, count); else launch_naive<VOL, false, false>(ctx, L, V, grid, count); }
 }
 
+// Tiles are dealt to the launch (and, at N > 1, to the ranks) heaviest first.  The frame is ~70 %
+// empty and a dense ray ends after 2 steps while a grazing one takes 513, so with ~10 working waves
+// per SIMD the kernel's tail is set by whichever heavy tiles start last; starting them first (and
+// round-robining them over ranks) shortens it.  The cost estimate is the nominal step count of a
+// 3x3 grid of rays per tile, from the same camera maths as the kernel, in double precision on the
+// host.  It is only a launch order: every tile is rendered by the same kernel whatever its rank.
+static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                             float dt_scale) {
+    const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
+    const size_t n = (size_t)tx * ty;
+    std::vector<unsigned char> key(144 + 40);
+    std::memcpy(key.data(), ctx->camera, 144);
+    const uint32_t kk[10] = {(uint32_t)mode, (uint32_t)ox, (uint32_t)oy, rw, rh, ts, ctx->width, ctx->height, ctx->nx ^ (ctx->ny << 10) ^ (ctx->nz << 20), 0};
+    std::memcpy(key.data() + 144, kk, 40);
+    (void)dt_scale;
+    if (key == ctx->order_key && ctx->order.size() == n) return VK_OK;
+    const float *cam = ctx->camera;
+    const double W = ctx->width, H = ctx->height;
+    std::vector<double> cost(n, 0.0);
+    auto mul = [&](const float *m, double x, double y, double z, double w, double o[4]) {
+        for (int r = 0; r < 4; r++) o[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
+    };
+    const double dims[3] = {(double)ctx->nx, (double)ctx->ny, (double)ctx->nz};
+    for (uint32_t j = 0; j < ty; j++)
+        for (uint32_t i = 0; i < tx; i++) {
+            double c = 0.0;
+            for (int sy = 0; sy < 3; sy++)
+                for (int sx = 0; sx < 3; sx++) {
+                    double px = ox + (double)i * ts + (2 * sx + 1) * ts / 6.0, py = oy + (double)j * ts + (2 * sy + 1) * ts / 6.0;
+                    if (px < 0 || py < 0 || px >= W || py >= H) continue;
+                    double e[3], d[3], lo, hi;
+                    if (mode == VK_MODE_NAIVE_TRILINEAR) {
+                        double q[4];
+                        mul(cam + 20, 2.0 * px / W - 1.0, 1.0 - 2.0 * py / H, 1.0, 1.0, q);
+                        for (int k = 0; k < 3; k++) { e[k] = cam[k]; d[k] = q[k] / q[3] - e[k]; }
+                        lo = 0.0; hi = 1.0;
+                    } else {
+                        double a[4], b[4], sxn = 2.0 * px / W - 1.0, syn = (2.0 * py / H - 1.0) * -(H / W);
+                        mul(cam + 20, sxn, syn, 0.0, 1.0, a);
+                        mul(cam + 20, sxn, syn, 1.0, 1.0, b);
+                        for (int k = 0; k < 3; k++) { e[k] = a[k] / a[3]; d[k] = b[k] / b[3] - e[k]; }
+                        lo = -1.0; hi = 1.0;
+                    }
+                    double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    if (!(len > 0)) continue;
+                    double t0 = -1e300, t1 = 1e300, dtm = 1e300;
+                    for (int k = 0; k < 3; k++) {
+                        d[k] /= len;
+                        double inv = 1.0 / d[k], ta = (lo - e[k]) * inv, tb = (hi - e[k]) * inv;
+                        t0 = std::max(t0, std::min(ta, tb));
+                        t1 = std::min(t1, std::max(ta, tb));
+                        dtm = std::min(dtm, 1.0 / (dims[k] * std::fabs(d[k])));
+                    }
+                    t0 = std::max(t0, 0.0);
+                    if (t1 > t0 && dtm > 0) c += (t1 - t0) / dtm;
+                }
+            cost[(size_t)j * tx + i] = c;
+        }
+    ctx->order.resize(n);
+    for (size_t t = 0; t < n; t++) ctx->order[t] = (uint32_t)t;
+    std::stable_sort(ctx->order.begin(), ctx->order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    ctx->order_pos.resize(n);
+    for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
+    if (ctx->d_order_cap < n) {
+        if (ctx->d_order) (void)hipFree(ctx->d_order);
+        if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
+        ctx->d_order = ctx->d_order_pos = nullptr;
+        ctx->d_order_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_order, n * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_order_pos, n * sizeof(uint32_t)));
+        ctx->d_order_cap = n;
+    }
+    // earlier launches may still read the old table: these copies are stream-ordered behind them
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors may be rewritten by the next call
+    ctx->order_key = key;
+    return VK_OK;
+}
+
 static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
                          uint32_t rank, uint32_t nranks, float dt_scale, uint32_t flags, void *compact_out) {
     if (!ctx) return VK_ERR_INVALID;
@@ -447,6 +536,11 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.tiles_x = (rw + ts - 1) / ts;
     L.tiles_y = (rh + ts - 1) / ts;
     L.rank = rank; L.nranks = nranks;
+    {
+        int orc = tile_order_update(ctx, mode, ox, oy, rw, rh, ts, dt_scale);
+        if (orc) return orc;
+        L.tile_order = ctx->d_order;
+    }
     const uint64_t tiles = (uint64_t)L.tiles_x * L.tiles_y;
     const uint64_t slots = (tiles + nranks - 1) / nranks;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
@@ -518,19 +612,36 @@ int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank
     return render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
 }
 
+int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *order_out, uint32_t n_tiles) {
+    if (!ctx || !order_out) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: NULL argument");
+    if (!ctx->backbuffer || !ctx->have_camera || ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: needs volume, camera and backbuffer");
+    if (tile_size == 0 || (tile_size & 7u)) return fail(ctx, VK_ERR_INVALID, "tile size must be a multiple of 8");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int orc = tile_order_update(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+    if (orc) return orc;
+    if (n_tiles != ctx->order.size()) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: n_tiles does not match the partition");
+    std::memcpy(order_out, ctx->order.data(), n_tiles * sizeof(uint32_t));
+    return VK_OK;
+}
+
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks) {
     if (!ctx || !gathered) return fail(ctx, VK_ERR_INVALID, "vk_untile: NULL argument");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
     uint32_t n_slots = 0;
     if (vk_partition_slots(ctx->width, ctx->height, tile_size, nranks, &n_slots)) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "vk_untile: no camera (the tile order follows the camera)");
+    {
+        int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+        if (orc) return orc;
+    }
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos);
     else
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos);
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
 }
@@ -559,10 +670,20 @@ int vk_step_counts(vk_ctx *ctx, uint64_t *s_ref, uint64_t *s_sampled) {
     return VK_OK;
 }
 
+int vk_simt_census(vk_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return fail(ctx, VK_ERR_INVALID, "vk_simt_census: NULL argument");
+    unsigned long long h[8] = {0};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; i++) out[i] = h[2 + i];
+    return VK_OK;
+}
+
 int vk_step_counts_reset(vk_ctx *ctx) {
     if (!ctx) return VK_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     return VK_OK;
 }
 

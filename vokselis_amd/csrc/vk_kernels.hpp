@@ -58,6 +58,7 @@ struct LaunchDesc {
     uint32_t n_blocks;   // logical 8x8 blocks of this launch
     uint32_t compact;    // 1: output is [slot][ts][ts], 0: [H][W]
     float dt_scale;
+    const uint32_t *tile_order;  // position in the heaviest-first order -> tile id (row-major)
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled}
@@ -85,14 +86,16 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, uint32_t lb, 
     uint32_t sps = L.ts >> 3;              // 8x8 blocks per tile edge
     uint32_t per_tile = sps * sps;
     uint32_t slot = lb / per_tile, sub = lb - slot * per_tile;
-    uint32_t tile = L.rank + slot * L.nranks;
+    uint32_t pos = L.rank + slot * L.nranks;  // position in the heaviest-first order
+    const uint32_t n_tiles = L.tiles_x * L.tiles_y;
+    uint32_t tile = pos < n_tiles ? L.tile_order[pos] : n_tiles;
     uint32_t tty = tile / L.tiles_x, ttx = tile - tty * L.tiles_x;
     uint32_t sy = sub / sps, sx = sub - sy * sps;
     uint32_t lx = sx * 8 + (lane & 7u), ly = sy * 8 + (lane >> 3);  // inside the tile
     uint32_t rx = ttx * L.ts + lx, ry = tty * L.ts + ly;             // inside the region
     m.x = L.ox + (int32_t)rx;
     m.y = L.oy + (int32_t)ry;
-    m.valid = (tile < L.tiles_x * L.tiles_y) && rx < L.rw && ry < L.rh && m.x >= 0 && m.y >= 0 &&
+    m.valid = (tile < n_tiles) && rx < L.rw && ry < L.rh && m.x >= 0 && m.y >= 0 &&
               m.x < (int32_t)L.W && m.y < (int32_t)L.H;
     m.out_index = L.compact ? ((size_t)slot * L.ts + ly) * L.ts + lx : (size_t)m.y * L.W + (size_t)m.x;
     return m;
@@ -206,6 +209,11 @@ __device__ __forceinline__ int med3_i32(int v, int lo, int hi) {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// true on exactly one active lane of the wave (instrumentation in COUNT builds only)
+__device__ __forceinline__ bool wave_leader() {
+    return (int)(threadIdx.x & 63u) == __ffsll((unsigned long long)__ballot(1)) - 1;
+}
+
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     float t0, t1;
     intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
     uint32_t n_iter = 0, n_samp = 0;
+    uint32_t w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0;  // SIMT execution census (COUNT builds)
     // colour is accumulated as G = sum w*cos(phase); C = 0.5*A + 0.5*G at the end (sum w == A)
     float Gr = 0.0f, Gg = 0.0f, Gb = 0.0f, A = 0.0f;
     float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
 
         float t = t0;
         while (t < t1) {  // :101
+            if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
             const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
             int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
             const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
                         px = px + sx; py = py + sy; pz = pz + sz;
                         t = t + dt;
-                        if (COUNT) n_iter++;
+                        if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
                     } while (--k > 0 && t < t1);
                     continue;
                 }
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             const float cr = __builtin_amdgcn_cosf(a * pc0);
             const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
             const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
-            if (COUNT) { n_iter++; n_samp++; }
+            if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
             const float w = (1.0f - A) * a;  // :112-114
             Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
             A = A + w;
@@ -364,6 +374,10 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         if (L.counters) {
             atomicAdd(&L.counters[0], (unsigned long long)n_iter);
             atomicAdd(&L.counters[1], (unsigned long long)n_samp);
+            atomicAdd(&L.counters[2], (unsigned long long)w_outer);
+            atomicAdd(&L.counters[3], (unsigned long long)w_inner);
+            atomicAdd(&L.counters[4], (unsigned long long)w_sample);
+            atomicAdd(&L.counters[5], (unsigned long long)n_look);
         }
     }
 }
@@ -631,12 +645,13 @@ __global__ __launch_bounds__(256) void clear_kernel(void *out, uint64_t n_px) {
 template <int OUT>
 __global__ __launch_bounds__(256) void untile_kernel(const void *__restrict__ gathered, void *__restrict__ out,
                                                      uint32_t W, uint32_t H, uint32_t ts, uint32_t tiles_x,
-                                                     uint32_t nranks, uint32_t n_slots) {
+                                                     uint32_t nranks, uint32_t n_slots,
+                                                     const uint32_t *__restrict__ tile_pos) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (uint64_t)W * H) return;
     uint32_t x = (uint32_t)(id % W), y = (uint32_t)(id / W);
-    uint32_t tile = (y / ts) * tiles_x + (x / ts);
-    uint32_t rank = tile % nranks, slot = tile / nranks;
+    uint32_t pos = tile_pos[(y / ts) * tiles_x + (x / ts)];  // tile id -> position in the order
+    uint32_t rank = pos % nranks, slot = pos / nranks;
     size_t src = (((size_t)rank * n_slots + slot) * ts + (y % ts)) * ts + (x % ts);
     if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];
     else reinterpret_cast<uint2 *>(out)[id] = reinterpret_cast<const uint2 *>(gathered)[src];

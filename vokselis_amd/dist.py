@@ -24,14 +24,17 @@ def tiles_xy(width: int, height: int, tile_size: int):
     return (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
 
 
-def tile_owner(tile: int, world: int) -> int:
-    return tile % world
+def tile_owner(pos: int, world: int) -> int:
+    """Rank owning position `pos` of the tile order."""
+    return pos % world
 
 
-def local_tiles(width: int, height: int, tile_size: int, rank: int, world: int):
-    """Tiles of this rank in slot order: slot j <-> tile rank + j*world."""
+def local_tiles(width: int, height: int, tile_size: int, rank: int, world: int, order=None):
+    """Row-major tile ids of this rank in slot order: slot j <-> position rank + j*world of `order`
+    (the library's heaviest-first order, `Context.partition_order`; identity when None)."""
     tx, ty = tiles_xy(width, height, tile_size)
-    return list(range(rank, tx * ty, world))
+    pos = range(rank, tx * ty, world)
+    return list(pos) if order is None else [int(order[q]) for q in pos]
 
 
 def n_slots(width: int, height: int, tile_size: int, world: int) -> int:
@@ -111,14 +114,15 @@ class TileParallelRenderer:
         self._finish_pending()
 
 
-def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int) -> np.ndarray:
+def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None) -> np.ndarray:
     """numpy statement of vk_untile: [world, n_slots, ts, ts, C] -> [H, W, C]."""
     world = gathered.shape[0]
-    tx, _ = tiles_xy(width, height, tile_size)
+    tx, ty = tiles_xy(width, height, tile_size)
+    pos = np.arange(tx * ty) if order is None else np.argsort(np.asarray(order))  # tile id -> position
     out = np.zeros((height, width, gathered.shape[-1]), gathered.dtype)
     for y0 in range(0, height, tile_size):
         for x0 in range(0, width, tile_size):
-            t = (y0 // tile_size) * tx + x0 // tile_size
+            q = int(pos[(y0 // tile_size) * tx + x0 // tile_size])
             h, w = min(tile_size, height - y0), min(tile_size, width - x0)
-            out[y0:y0 + h, x0:x0 + w] = gathered[t % world, t // world, :h, :w]
+            out[y0:y0 + h, x0:x0 + w] = gathered[q % world, q // world, :h, :w]
     return out
