@@ -47,6 +47,9 @@ struct vk_ctx {
     // heaviest-first tile order (launch-order heuristic; see tile_order_update)
     std::vector<uint32_t> order, order_pos;
     std::vector<unsigned char> order_key;
+    unsigned long long *trace = nullptr;
+    size_t trace_blocks = 0;
+    bool want_trace = false;
     uint32_t *d_order = nullptr, *d_order_pos = nullptr;
     size_t d_order_cap = 0;
 
@@ -136,6 +139,7 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
     if (ctx->steps) (void)hipFree(ctx->steps);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->trace) (void)hipFree(ctx->trace);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -479,7 +483,8 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     ctx->order_pos.resize(n);
     for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
     if (ctx->d_order_cap < n) {
-        if (ctx->d_order) (void)hipFree(ctx->d_order);
+        if (ctx->trace) (void)hipFree(ctx->trace);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
         if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
         ctx->d_order = ctx->d_order_pos = nullptr;
         ctx->d_order_cap = 0;
@@ -535,6 +540,28 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.ts = ts;
     L.tiles_x = (rw + ts - 1) / ts;
     L.tiles_y = (rh + ts - 1) / ts;
+    // screen-space bounding rectangle of the unit cube (NAIVE mode): project the 8 corners with
+    // proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
+    L.cull_x0 = 0; L.cull_y0 = 0; L.cull_x1 = (int32_t)ctx->width; L.cull_y1 = (int32_t)ctx->height;
+    if (mode == VK_MODE_NAIVE_TRILINEAR) {
+        const float *pv = ctx->camera + 4;
+        double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+        bool ok = true;
+        for (int c = 0; c < 8 && ok; c++) {
+            const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
+            const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
+            const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
+            if (!(cw > 1e-6)) { ok = false; break; }
+            const double sx = (cx / cw * 0.5 + 0.5) * ctx->width, sy = (0.5 - cy / cw * 0.5) * ctx->height;
+            x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
+        }
+        if (ok && std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1)) {
+            L.cull_x0 = (int32_t)std::max(0.0, std::floor(x0) - 2.0);
+            L.cull_y0 = (int32_t)std::max(0.0, std::floor(y0) - 2.0);
+            L.cull_x1 = (int32_t)std::min((double)ctx->width, std::ceil(x1) + 2.0);
+            L.cull_y1 = (int32_t)std::min((double)ctx->height, std::ceil(y1) + 2.0);
+        }
+    }
     L.rank = rank; L.nranks = nranks;
     {
         int orc = tile_order_update(ctx, mode, ox, oy, rw, rh, ts, dt_scale);
@@ -552,6 +579,20 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.out = compact_out ? compact_out : ctx->backbuffer;
     L.steps = count ? ctx->steps : nullptr;
     L.counters = count ? ctx->counters : nullptr;
+    L.trace = nullptr;
+    if (count && ctx->want_trace) {
+        if (ctx->trace_blocks < n_blocks) {
+            if (ctx->trace) (void)hipFree(ctx->trace);
+            ctx->trace = nullptr; ctx->trace_blocks = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 2 * sizeof(unsigned long long)));
+            ctx->trace_blocks = n_blocks;
+        }
+        // start = +inf (atomicMin), end = 0 (atomicMax): fill {0xff.., 0} pairs
+        std::vector<unsigned long long> init(n_blocks * 2);
+        for (uint64_t i = 0; i < n_blocks; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+        HIP_TRY(ctx, hipMemcpy(ctx->trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        L.trace = ctx->trace;
+    }
     VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
@@ -677,6 +718,17 @@ int vk_simt_census(vk_ctx *ctx, uint64_t out[4]) {
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 4; i++) out[i] = h[2 + i];
+    return VK_OK;
+}
+
+int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks) {
+    if (!ctx) return VK_ERR_INVALID;
+    ctx->want_trace = enable != 0;
+    if (!out) return VK_OK;
+    if (!ctx->trace || n_blocks > ctx->trace_blocks) return fail(ctx, VK_ERR_INVALID, "vk_debug_wave_trace: no trace of that size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->trace, n_blocks * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VK_OK;
 }
 

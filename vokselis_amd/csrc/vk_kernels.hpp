@@ -59,9 +59,11 @@ struct LaunchDesc {
     uint32_t compact;    // 1: output is [slot][ts][ts], 0: [H][W]
     float dt_scale;
     const uint32_t *tile_order;  // position in the heaviest-first order -> tile id (row-major)
+    int32_t cull_x0, cull_y0, cull_x1, cull_y1;  // pixels outside [x0,x1) x [y0,y1) cannot hit the box
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
-    unsigned long long *counters;  // optional {S_ref, S_sampled}
+    unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
+    unsigned long long *trace;     // optional per-block {start, end} s_memrealtime stamps (COUNT builds)
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------
@@ -221,8 +223,20 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
+    unsigned long long t_start = 0;
+    if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
     const PixelMap pm = map_pixel(L, lb, lane);
     if (!pm.valid) return;
+    {
+        // Screen-space cull (wave-uniform): an 8x8 block wholly outside the projected cube's bounding
+        // rectangle (host-computed, padded) holds only misses: clear colour, no ray set-up.
+        const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
+        if (bx0 + 8 <= L.cull_x0 || bx0 >= L.cull_x1 || by0 + 8 <= L.cull_y0 || by0 >= L.cull_y1) {
+            store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
+            if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
+            return;
+        }
+    }
 
     // --- ray: SURVEY A.1 step 1 (replaces vs_main + rasteriser) ---
     float fxp = (float)pm.x + 0.5f, fyp = (float)pm.y + 0.5f;
@@ -254,7 +268,9 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
 
         // per-ray constants of the skip bound (see below)
         float idux = 0.f, iduy = 0.f, iduz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f, kpx = 0.f, kpy = 0.f, kpz = 0.f;
+        float inv_dt = 0.f;
         if (SKIP) {
+            inv_dt = __builtin_amdgcn_rcpf(dt);  // only bounds a skip length (2 steps of slack below)
             idux = 1.0f / (fabsf(sx) * fnx); iduy = 1.0f / (fabsf(sy) * fny); iduz = 1.0f / (fabsf(sz) * fnz);
             sgx = sx >= 0.0f ? -1.0f : 1.0f; sgy = sy >= 0.0f ? -1.0f : 1.0f; sgz = sz >= 0.0f ? -1.0f : 1.0f;
             // margin 0.02 cells covers the rounding of the accumulated position (<= 1e-3 cells)
@@ -294,13 +310,17 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     const float rx = fmaf(sgx, fx, fd + kpx) * idux;
                     const float ry = fmaf(sgy, fy, fd + kpy) * iduy;
                     const float rz = fmaf(sgz, fz, fd + kpz) * iduz;
-                    int k = (int)fminf(rx, fminf(ry, rz));  // NaN -> 0, saturating
+                    // ... and never past the ray's end: iterations j <= (t1 - t)/dt - 2 certainly see
+                    // t < t1, so the walk needs no float compare; the last couple of iterations of a
+                    // ray fall back to single steps, where the loop's own `t < t1` test decides.
+                    const float rend = fmaf(t1 - t, inv_dt, -2.0f);
+                    int k = (int)fminf(fminf(rx, rend), fminf(ry, rz));  // NaN -> 0, saturating
                     k = max(k, 0) + 1;  // the current sample is always skippable (its cell is empty)
                     do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
                         px = px + sx; py = py + sy; pz = pz + sz;
                         t = t + dt;
                         if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
-                    } while (--k > 0 && t < t1);
+                    } while (--k > 0);
                     continue;
                 }
                 if (VOL == VOL_P8) {
@@ -378,6 +398,11 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             atomicAdd(&L.counters[3], (unsigned long long)w_inner);
             atomicAdd(&L.counters[4], (unsigned long long)w_sample);
             atomicAdd(&L.counters[5], (unsigned long long)n_look);
+        }
+        if (L.trace) {  // stamps leave only through this debug buffer
+            unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            atomicMin(&L.trace[2 * (size_t)lb], t_start);
+            atomicMax(&L.trace[2 * (size_t)lb + 1], t_end);
         }
     }
 }
