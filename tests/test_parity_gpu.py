@@ -319,3 +319,33 @@ def test_headless_demo_loop(V, O):
         assert len(buf) == dims.linear_size() and dims.padded_bytes_per_row == 768
     finally:
         ctx.close()
+
+
+def test_cpp_host_bonsai_example(V, O, tmp_path):
+    """The compiled C++ host (vokselis_amd/host: Context / Demo / run_headless / bonsai) drives the same
+    C-ABI; its captured frame matches the oracle's frame after the same 8-bit quantisation."""
+    import os
+    import subprocess
+
+    import __graft_entry__ as g
+
+    g.build_host()
+    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "bonsai")
+    ppm = tmp_path / "bonsai.ppm"
+    r = subprocess.run([exe, "--frames", "3", "--size", "320x180", "--dt", "1.0", "--ppm", str(ppm)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Avg frame time" in r.stdout and "gfx950" in r.stdout
+    raw = ppm.read_bytes()
+    hdr, data = raw.split(b"\n255\n", 1)
+    assert hdr == b"P6\n320 180"
+    img = np.frombuffer(data, np.uint8).reshape(180, 320, 3).astype(np.int32)
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 320 / 180).get_proj_view_matrix()
+    ref, _, _ = O.render(cam, O.volume_standin_u8(256), 320, 180, dt_scale=1.0)
+    # the surface is rgba16f: quantise the oracle through f16 first, like the backbuffer
+    ref16 = O.rgba32f_to_rgba16f(ref).view(np.float16).astype(np.float32)
+    want = (np.clip(ref16[..., :3], 0, 1) * 255.0 + 0.5).astype(np.int32)
+    d = np.abs(img - want)
+    assert d.max() <= 2 and (d == 0).mean() > 0.99
+    # a missing GPU library / device is an error exit, not a silent fallback
+    r = subprocess.run([exe, "--raw", "/nonexistent.raw", "--frames", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open" in r.stderr
