@@ -180,7 +180,14 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
     // d_src is dense device memory; for LINEAR / PAIR with own_src the context adopts it.
     const size_t n_vox = (size_t)nx * ny * nz;
     const size_t bpv = format == VK_FMT_R8_UNORM ? 1 : (format == VK_FMT_R16_FLOAT ? 2 : 8);
-    if (layout == VK_LAYOUT_AUTO) layout = format == VK_FMT_RGBA16F_PAIR ? VK_LAYOUT_LINEAR : VK_LAYOUT_PACKED;
+    if (layout == VK_LAYOUT_AUTO) {
+        // u8: the (tap, delta) pair cells cost 2x the bytes and ~20 % fewer VALU ops per sample; take
+        // them while cells + skip map + build scratch stay well inside the GPU's memory
+        const double cells = ((double)((nx - 1) / 4 + 2)) * ((ny - 1) / 4 + 2) * ((nz - 1) / 4 + 2) * 64.0;
+        if (format == VK_FMT_RGBA16F_PAIR) layout = VK_LAYOUT_LINEAR;
+        else if (format == VK_FMT_R8_UNORM && cells * 18.0 + (double)n_vox < 0.6 * (double)ctx->prop.totalGlobalMem) layout = VK_LAYOUT_PACKED_PAIRS;
+        else layout = VK_LAYOUT_PACKED;
+    }
     if (format == VK_FMT_RGBA16F_PAIR && layout != VK_LAYOUT_LINEAR)
         return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR volumes use the linear layout (nearest-neighbour loads)");
     free_volume(ctx);
@@ -255,6 +262,10 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
     V.kz = (64 * bxyn - 64) * cb;
     V.c0 = (64 * bxyn + 64 * bxn + 64) * cb;
     V.max_off = (int64_t)(n_cells - 1) * cb;
+    V.ci0 = (int32_t)std::min<int64_t>(64 * bxyn + 64 * bxn + 64, INT32_MAX);
+    V.ciy = (int32_t)std::min<int64_t>(64 * bxn - 16, (1 << 23) - 1);
+    V.ciz = (int32_t)std::min<int64_t>(64 * bxyn - 64, (1 << 23) - 1);
+    V.max_idx = (uint32_t)std::min<uint64_t>(n_cells - 1, 0xffffffffu);
     return VK_OK;
 }
 
@@ -618,7 +629,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
             float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
             float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
             float ulp = std::nextafter(reach, 2.0f * reach) - reach;
-            if (V.max_off + 16 < (1ll << 31) && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
+            if (V.max_off + 16 < (1ll << 31) && 64 * (int64_t)ctx->nbx * ctx->nby < (1 << 23) && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
         }
         switch (ctx->vol_kind) {
             case VOL_P8: launch_packed<VOL_P8>(ctx, L, V, grid, count, skip, safe); break;

@@ -44,6 +44,10 @@ struct VolumeDesc {
     int64_t kz, c0, max_off;
     int32_t kx, ky;
     uint32_t sh_x, sh_y, sh_z;
+    // the same in cell units (SAFE=false path): idx = ci0 + (ix + 60*bx) + (4*iy + ciy*by) + (16*iz + ciz*bz)
+    // (an inline-asm v_mad_i32_i24 chain was 3-5 % slower than what hipcc schedules for this expression)
+    int32_t ci0, ciy, ciz;
+    uint32_t max_idx;
 };
 
 struct LaunchDesc {
@@ -203,6 +207,12 @@ __device__ __forceinline__ int cvt_floor_i32(float u) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
     return i;
 }
+// float -> u32, saturating: negatives and NaN give 0 (C++ leaves that conversion undefined)
+__device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
 __device__ __forceinline__ int med3_i32(int v, int lo, int hi) {
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
@@ -267,14 +277,17 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
 
         // per-ray constants of the skip bound (see below)
-        float idux = 0.f, iduy = 0.f, iduz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f, kpx = 0.f, kpy = 0.f, kpz = 0.f;
+        // Skip bound per axis: room_i / |du_i| with room_i = d - f_i (moving up) or f_i + d - 1 (moving
+        // down), minus a 0.02-cell margin that covers the rounding of the accumulated position
+        // (<= 1e-3 cells); folded into two fmas: r_i = f_i * ska_i + (d * idu_i + skb_i).
+        float idux = 0.f, iduy = 0.f, iduz = 0.f, skax = 0.f, skay = 0.f, skaz = 0.f, skbx = 0.f, skby = 0.f, skbz = 0.f;
         float inv_dt = 0.f;
         if (SKIP) {
             inv_dt = __builtin_amdgcn_rcpf(dt);  // only bounds a skip length (2 steps of slack below)
             idux = 1.0f / (fabsf(sx) * fnx); iduy = 1.0f / (fabsf(sy) * fny); iduz = 1.0f / (fabsf(sz) * fnz);
-            sgx = sx >= 0.0f ? -1.0f : 1.0f; sgy = sy >= 0.0f ? -1.0f : 1.0f; sgz = sz >= 0.0f ? -1.0f : 1.0f;
-            // margin 0.02 cells covers the rounding of the accumulated position (<= 1e-3 cells)
-            kpx = sx >= 0.0f ? -0.02f : -1.02f; kpy = sy >= 0.0f ? -0.02f : -1.02f; kpz = sz >= 0.0f ? -0.02f : -1.02f;
+            skax = sx >= 0.0f ? -idux : idux; skay = sy >= 0.0f ? -iduy : iduy; skaz = sz >= 0.0f ? -iduz : iduz;
+            skbx = (sx >= 0.0f ? -0.02f : -1.02f) * idux; skby = (sy >= 0.0f ? -0.02f : -1.02f) * iduy;
+            skbz = (sz >= 0.0f ? -0.02f : -1.02f) * iduz;
         }
 
         float t = t0;
@@ -296,26 +309,27 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     cptr = reinterpret_cast<const char *>(V.data) + off;
                     if (SKIP) d = V.dist[off >> V.sh_x];
                 } else {
-                    uint32_t off = (uint32_t)(bz * (int)V.kz + by * (int)V.ky + bx * (int)V.kx + (iz << V.sh_z) +
-                                              (iy << V.sh_y) + (ix << V.sh_x) + (int)V.c0);
-                    off = min(off, (uint32_t)V.max_off);  // memory-safety net; never binds for valid rays
-                    cptr = reinterpret_cast<const char *>(V.data) + off;
-                    if (SKIP) d = V.dist[off >> V.sh_x];
+                    // cell index, affine in (i, i >> 2)
+                    const uint32_t acc = (uint32_t)(bz * V.ciz + by * V.ciy + bx * 60 + (iz << 4) + (iy << 2) + ix + V.ci0);
+                    const uint32_t idx = min(acc, V.max_idx);  // memory-safety net; never binds for valid rays
+                    cptr = reinterpret_cast<const char *>(V.data) + (uint32_t)(idx << V.sh_x);  // < 2 GiB: SGPR base + 32-bit offset
+                    if (SKIP) d = V.dist[idx];
                 }
                 if (SKIP && d != 0) {
                     // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
                     // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
                     // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margin.
                     const float fd = (float)d;
-                    const float rx = fmaf(sgx, fx, fd + kpx) * idux;
-                    const float ry = fmaf(sgy, fy, fd + kpy) * iduy;
-                    const float rz = fmaf(sgz, fz, fd + kpz) * iduz;
+                    const float rx = fmaf(fx, skax, fmaf(fd, idux, skbx));
+                    const float ry = fmaf(fy, skay, fmaf(fd, iduy, skby));
+                    const float rz = fmaf(fz, skaz, fmaf(fd, iduz, skbz));
                     // ... and never past the ray's end: iterations j <= (t1 - t)/dt - 2 certainly see
                     // t < t1, so the walk needs no float compare; the last couple of iterations of a
                     // ray fall back to single steps, where the loop's own `t < t1` test decides.
                     const float rend = fmaf(t1 - t, inv_dt, -2.0f);
-                    int k = (int)fminf(fminf(rx, rend), fminf(ry, rz));  // NaN -> 0, saturating
-                    k = max(k, 0) + 1;  // the current sample is always skippable (its cell is empty)
+                    // float -> u32 conversion saturates negatives and NaN to 0; +1: the current sample is
+                    // always skippable (its cell is empty)
+                    uint32_t k = cvt_u32_sat(fminf(fminf(rx, rend), fminf(ry, rz))) + 1u;
                     do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
                         px = px + sx; py = py + sy; pz = pz + sz;
                         t = t + dt;
