@@ -128,6 +128,17 @@ int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *orde
 /* Root side: scatter the gathered [nranks][n_slots][ts][ts] pixels into the backbuffer. */
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks);
 
+/* ---- present + screenshot ---------------------------------------- */
+/* Context::render's present pass (src/context.rs:251-297, shaders/present.wgsl:23-35,111-119): bilinear
+ * resample of the backbuffer to width x height (the window size), ACESFilm, linear_to_srgb, into the
+ * context-owned Rgba8Unorm target (and a Bgra8Unorm "surface" copy when also_bgra != 0).  Asynchronous. */
+int vk_present(vk_ctx *ctx, uint32_t width, uint32_t height, int also_bgra);
+/* Context::capture_frame (src/context.rs:299-302, src/context/screenshot.rs:37-77): the presented Rgba8
+ * image with the reference's ImageDimentions: even-rounded size, rows padded to 256 B.  dst == NULL only
+ * queries the three sizes.  Blocking. */
+int vk_capture_frame(vk_ctx *ctx, void *dst, size_t dst_bytes, uint32_t *out_width, uint32_t *out_height,
+                     uint32_t *out_padded_bytes_per_row);
+
 /* ---- results ----------------------------------------------------------------------------- */
 /* ScreenshotCtx::capture_frame's copy_texture_to_buffer + map, src/context/screenshot.rs:37-77.
  * Blocking.  row_pitch_bytes >= width * bytes_per_pixel. */

@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         L.vo_dispatch_optimal.argtypes = [C.c_uint32, C.c_uint32]
         L.vo_dispatch_optimal.restype = C.c_uint32
         L.vo_image_dimentions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.vo_present.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.vo_ray_naive.argtypes = [C.POINTER(CameraUniform), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vo_ray_compute.argtypes = [C.POINTER(CameraUniform), C.c_uint32, C.c_uint32, C.c_float, C.c_float,
@@ -193,3 +194,11 @@ def volume_fog_f16(n, seed=0x5EED0004) -> np.ndarray:
     out = np.empty((nz, ny, nx), np.uint16)
     lib().vo_volume_fog_f16(nx, ny, nz, seed, out.ctypes.data)
     return out.view(np.float16)
+
+
+def present(backbuffer: np.ndarray, width: int, height: int) -> np.ndarray:
+    """Present pass (present.wgsl): backbuffer [bh,bw,4] f32 -> [height,width,4] u8 RGBA."""
+    bb = np.ascontiguousarray(backbuffer, np.float32)
+    out = np.empty((height, width, 4), np.uint8)
+    lib().vo_present(bb.ctypes.data, bb.shape[1], bb.shape[0], width, height, out.ctypes.data)
+    return out

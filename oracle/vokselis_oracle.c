@@ -534,6 +534,51 @@ int vo_render(const vo_render_args *a) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* Present pass: shaders/present.wgsl                                         */
+
+static inline float aces_film(float x) { /* present.wgsl:33-35 */
+    float num = x * (2.51f * x + 0.03f);
+    float den = x * (2.43f * x + 0.59f) + 0.14f;
+    return vmin(vmax(num / den, 0.0f), 1.0f);
+}
+
+static inline float present_srgb(float c) { /* present.wgsl:23-30: branch-free, exponent 0.41666 */
+    float sel = ceilf(c - 0.0031308f);
+    float under = 12.92f * c;
+    float over = 1.055f * powf(c, 0.41666f) - 0.055f;
+    return under * (1.0f - sel) + over * sel; /* mix(under, over, sel) */
+}
+
+void vo_present(const float *bb, uint32_t bw, uint32_t bh, uint32_t w, uint32_t h, uint8_t *out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t y = 0; y < (int64_t)h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            /* fullscreen triangle (present.wgsl:98-104): uv at the pixel centre */
+            float uvx = ((float)x + 0.5f) / (float)w, uvy = ((float)y + 0.5f) / (float)h;
+            float ux = fmaf(uvx, (float)bw, -0.5f), uy = fmaf(uvy, (float)bh, -0.5f);
+            float flx = floorf(ux), fly = floorf(uy);
+            float fx = ux - flx, fy = uy - fly;
+            if (fx >= 1.0f) fx = 0x1.fffffep-1f;
+            if (fy >= 1.0f) fy = 0x1.fffffep-1f;
+            int ix = (int)flx, iy = (int)fly;
+            int x0 = clampi(ix, 0, (int)bw - 1), x1 = clampi(ix + 1, 0, (int)bw - 1);
+            int y0 = clampi(iy, 0, (int)bh - 1), y1 = clampi(iy + 1, 0, (int)bh - 1);
+            uint8_t *o = out + 4 * ((size_t)y * w + x);
+            for (int c = 0; c < 4; c++) {
+                float t00 = bb[4 * ((size_t)y0 * bw + x0) + c], t10 = bb[4 * ((size_t)y0 * bw + x1) + c];
+                float t01 = bb[4 * ((size_t)y1 * bw + x0) + c], t11 = bb[4 * ((size_t)y1 * bw + x1) + c];
+                float a = lerp_fma(t00, t10, fx), b = lerp_fma(t01, t11, fx);
+                float v = lerp_fma(a, b, fy);
+                if (c < 3) v = present_srgb(aces_film(v));
+                v = vmin(vmax(v, 0.0f), 1.0f);
+                o[c] = (uint8_t)floorf(v * 255.0f + 0.5f);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Deterministic volumes (integer-only)                                       */
 
 static inline uint32_t lowbias32(uint32_t x) {

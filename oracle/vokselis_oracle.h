@@ -118,6 +118,12 @@ void vo_volume_fog_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint
                       uint32_t span, uint8_t *out);
 void vo_volume_fog_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint16_t *out);
 
+/* Present pass (next row N1): shaders/present.wgsl:23-35,111-119 with the linear clamp-to-edge sampler of
+ * src/context/present_pipeline.rs:95-104.  backbuffer: [bh][bw][4] f32 (already rounded through f16
+ * by the caller when the surface is rgba16float); out: [h][w][4] u8 in RGBA order (the Rgba8Unorm
+ * copy that capture_frame reads, src/context.rs:339-359).  unorm8 = floor(c*255 + 0.5). */
+void vo_present(const float *backbuffer, uint32_t bw, uint32_t bh, uint32_t w, uint32_t h, uint8_t *out_rgba8);
+
 /* src/utils/mod.rs:15-18 and :99-117 */
 uint32_t vo_dispatch_optimal(uint32_t len, uint32_t subgroup);
 void vo_image_dimentions(uint32_t w, uint32_t h, uint32_t align, uint32_t out4[4]);

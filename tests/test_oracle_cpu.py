@@ -150,3 +150,24 @@ def test_nominal_step_counts_match_survey(O, cameras):
     assert abs((steps > 0).mean() - 0.543) < 0.002
     assert abs(steps.sum() / 2.16e7 - 1) < 0.01
     assert steps.max() == 257
+
+
+def test_present_oracle_basics(O):
+    """present.wgsl: ACESFilm + branch-free sRGB on a few known values, identity-size resample."""
+    bb = np.zeros((4, 6, 4), np.float32)
+    bb[..., 3] = 1.0
+    bb[1, 2, :3] = [0.5, 0.0031308, 10.0]
+    bb[2, 3, :3] = [0.001, 0.18, 1.0]
+    out = O.present(bb, 6, 4)
+    assert out.shape == (4, 6, 4) and (out[..., 3] == 255).all() and (out[0, 0, :3] == 0).all()
+
+    def ref(x):
+        a = min(max((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0.0), 1.0)
+        s = 12.92 * a if a <= 0.0031308 else 1.055 * a ** 0.41666 - 0.055
+        return int(np.floor(min(max(s, 0.0), 1.0) * 255 + 0.5))
+
+    for (y, x) in ((1, 2), (2, 3)):
+        assert [abs(int(out[y, x, c]) - ref(float(bb[y, x, c]))) <= 1 for c in range(3)] == [True] * 3
+    # downsampling by 2 averages 2x2 texel blocks (uv lands on texel corners)
+    small = O.present(np.full((8, 8, 4), 0.18, np.float32), 4, 4)
+    assert (small[..., :3] == ref(0.18)).all()

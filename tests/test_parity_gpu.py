@@ -315,7 +315,7 @@ def test_headless_demo_loop(V, O):
         assert calls == ["init"] + ["update", "render"] * 3
         ref, _, _ = O.render(cam.get_proj_view_matrix(), vol, 160, 90)
         assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL
-        buf, dims = ctx.capture_frame()
+        buf, dims = ctx.capture_frame()  # run_headless presents after every Demo.render, like the reference
         assert len(buf) == dims.linear_size() and dims.padded_bytes_per_row == 768
     finally:
         ctx.close()
@@ -341,11 +341,38 @@ def test_cpp_host_bonsai_example(V, O, tmp_path):
     img = np.frombuffer(data, np.uint8).reshape(180, 320, 3).astype(np.int32)
     cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 320 / 180).get_proj_view_matrix()
     ref, _, _ = O.render(cam, O.volume_standin_u8(256), 320, 180, dt_scale=1.0)
-    # the surface is rgba16f: quantise the oracle through f16 first, like the backbuffer
+    # the surface is rgba16f: quantise the oracle through f16 first, like the backbuffer, then present
     ref16 = O.rgba32f_to_rgba16f(ref).view(np.float16).astype(np.float32)
-    want = (np.clip(ref16[..., :3], 0, 1) * 255.0 + 0.5).astype(np.int32)
+    want = O.present(ref16, 320, 180)[..., :3].astype(np.int32)
     d = np.abs(img - want)
     assert d.max() <= 2 and (d == 0).mean() > 0.99
     # a missing GPU library / device is an error exit, not a silent fallback
     r = subprocess.run([exe, "--raw", "/nonexistent.raw", "--frames", "1"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+def test_present_pass_and_capture_frame(V, O):
+    """Next rows N1/N2: present.wgsl (bilinear resample, ACESFilm, branch-free sRGB, Rgba8) and
+    capture_frame's byte layout (even-rounded size, 256-B row pitch)."""
+    vol = O.volume_standin_u8(64)
+    for (bw, bh), (w, h) in [((160, 90), (160, 90)), ((160, 90), (213, 121)), ((128, 72), (64, 36)), ((96, 96), (95, 33))]:
+        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), w / h)
+        for fmt in (V.OUT_RGBA16F, V.OUT_RGBA32F):
+            ctx = V.Context(w, h, cam, backbuffer=(bw, bh), out_format=fmt)
+            try:
+                V.VolumeTexture(ctx, vol)
+                ctx.update()
+                V.RaycastPipeline(dt_scale=1.0).record(ctx)
+                ctx.render()
+                buf, dims = ctx.capture_frame()
+                assert (dims.width, dims.height) == (w - w % 2, h - h % 2) and dims.padded_bytes_per_row % 256 == 0
+                assert len(buf) == dims.linear_size()
+                rows = np.frombuffer(buf, np.uint8).reshape(dims.height, dims.padded_bytes_per_row)
+                got = rows[:, :dims.unpadded_bytes_per_row].reshape(dims.height, dims.width, 4).astype(np.int32)
+                assert (rows[:, dims.unpadded_bytes_per_row:] == 0).all()
+                want = O.present(ctx.read_backbuffer().astype(np.float32), w, h)[:dims.height, :dims.width].astype(np.int32)
+                d = np.abs(got - want)
+                assert d.max() <= 1 and (d == 0).mean() > 0.995, ((bw, bh), (w, h), fmt, d.max(), (d == 0).mean())
+                assert (got[..., 3] == 255).all()
+            finally:
+                ctx.close()

@@ -184,16 +184,20 @@ class Context:
         N.check(self._h, N.lib().vk_readback(self._h, out.ctypes.data, out.strides[0]))
         return out
 
+    def render(self):
+        """Context::render (src/context.rs:251-297): the present pass -- backbuffer -> ACES + sRGB ->
+        Rgba8 at the window size.  (No surface to present to on a compute node.)"""
+        N.check(self._h, N.lib().vk_present(self._h, self.width, self.height, 0))
+
     def capture_frame(self):
-        """Context::capture_frame, src/context.rs:299-302 / screenshot.rs:37-77: RGBA8 rows padded to
-        256 B.  The reference captures the tone-mapped present target; the present pass is a later
-        row, so this quantises the sRGB backbuffer directly."""
-        bb = self.render_backbuffer
-        dims = ImageDimentions.new(bb.width, bb.height, 256)
-        img = self.read_backbuffer().astype(np.float32)[: dims.height, : dims.width]
-        rgba8 = (np.clip(img, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
-        buf = np.zeros((dims.height, dims.padded_bytes_per_row), np.uint8)
-        buf[:, : dims.unpadded_bytes_per_row] = rgba8.reshape(dims.height, -1)
+        """Context::capture_frame (src/context.rs:299-302, screenshot.rs:37-77): the presented Rgba8
+        frame as padded rows + its ImageDimentions."""
+        w, h, pitch = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        N.check(self._h, N.lib().vk_capture_frame(self._h, None, 0, C.byref(w), C.byref(h), C.byref(pitch)))
+        dims = ImageDimentions.new(self.width, self.height, 256)
+        assert (dims.width, dims.height, dims.padded_bytes_per_row) == (w.value, h.value, pitch.value)
+        buf = np.zeros(dims.linear_size(), np.uint8)
+        N.check(self._h, N.lib().vk_capture_frame(self._h, buf.ctypes.data, buf.size, None, None, None))
         return buf.tobytes(), dims
 
     def partition_order(self, tile_size: int, mode: int = N.MODE_NAIVE_TRILINEAR) -> np.ndarray:
@@ -340,5 +344,6 @@ def run_headless(demo_cls, frames: int = 1, camera: Camera | None = None, width:
         demo.update(ctx)
         fc.record()
         demo.render(ctx)
+        ctx.render()  # src/lib.rs:178-182: demo.render, then context.render (present pass)
     ctx.sync()
     return ctx, demo

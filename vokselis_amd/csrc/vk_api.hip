@@ -53,6 +53,10 @@ struct vk_ctx {
     uint32_t *d_order = nullptr, *d_order_pos = nullptr;
     size_t d_order_cap = 0;
 
+    // present targets (next row N1/N2)
+    uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
+    uint32_t present_w = 0, present_h = 0;
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_open = false, timing_done = false;
 };
@@ -139,6 +143,8 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
     if (ctx->steps) (void)hipFree(ctx->steps);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->rgba8) (void)hipFree(ctx->rgba8);
+    if (ctx->bgra8) (void)hipFree(ctx->bgra8);
     if (ctx->trace) (void)hipFree(ctx->trace);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
@@ -695,6 +701,51 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
     else
         hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos);
     HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+// ---- present + capture (next rows N1, N2) ------------------------------------------------------
+
+int vk_present(vk_ctx *ctx, uint32_t width, uint32_t height, int also_bgra) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "vk_present: no backbuffer");
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, VK_ERR_INVALID, "vk_present: size must be in [1, 32768]");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (width != ctx->present_w || height != ctx->present_h || (also_bgra && !ctx->bgra8)) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->rgba8) (void)hipFree(ctx->rgba8);
+        if (ctx->bgra8) (void)hipFree(ctx->bgra8);
+        ctx->rgba8 = ctx->bgra8 = nullptr;
+        ctx->present_w = ctx->present_h = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->rgba8, (size_t)width * height * 4));
+        if (also_bgra) HIP_TRY(ctx, hipMalloc(&ctx->bgra8, (size_t)width * height * 4));
+        ctx->present_w = width; ctx->present_h = height;
+    }
+    const uint64_t n = (uint64_t)width * height;
+    hipLaunchKernelGGL(present_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->backbuffer,
+                       ctx->out_format == VK_OUT_RGBA16F ? OUT_RGBA16F : OUT_RGBA32F, ctx->width, ctx->height, width, height,
+                       ctx->rgba8, also_bgra ? ctx->bgra8 : nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_capture_frame(vk_ctx *ctx, void *dst, size_t dst_bytes, uint32_t *out_width, uint32_t *out_height,
+                     uint32_t *out_padded_bytes_per_row) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->rgba8) return fail(ctx, VK_ERR_INVALID, "vk_capture_frame: nothing presented yet (vk_present)");
+    // ImageDimentions::new(w, h, 256): even-rounded size, rows padded to 256 B (src/utils/mod.rs:99-113)
+    const uint32_t w = ctx->present_w - (ctx->present_w % 2), h = ctx->present_h - (ctx->present_h % 2);
+    const uint32_t unpadded = w * 4, padded = unpadded + (256 - unpadded % 256) % 256;
+    if (out_width) *out_width = w;
+    if (out_height) *out_height = h;
+    if (out_padded_bytes_per_row) *out_padded_bytes_per_row = padded;
+    if (!dst) return VK_OK;  // size query
+    if (dst_bytes < (size_t)padded * h) return fail(ctx, VK_ERR_INVALID, "vk_capture_frame: destination smaller than padded_bytes_per_row * height");
+    if (w == 0 || h == 0) return VK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::memset(dst, 0, (size_t)padded * h);
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, padded, ctx->rgba8, (size_t)ctx->present_w * 4, unpadded, h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VK_OK;
 }
 

@@ -680,6 +680,55 @@ __global__ __launch_bounds__(256) void clear_kernel(void *out, uint64_t n_px) {
     if (id < n_px) store_pixel<OUT>(out, id, 0.0f, 0.0f, 0.0f, 1.0f);
 }
 
+// ---- present pass (next row N1): shaders/present.wgsl:23-35,111-119 ---------------------------
+// One fused pass: bilinear resample of the backbuffer (linear clamp-to-edge sampler,
+// src/context/present_pipeline.rs:95-104) -> ACESFilm -> branch-free linear_to_srgb -> RGBA8 (the
+// Rgba8Unorm copy capture_frame reads) and, optionally, BGRA8 (the surface format).  HBM-bound:
+// 8-16 B read + 4-8 B written per pixel.
+__device__ __forceinline__ float4 load_px(const void *bb, int fmt, size_t idx) {
+    if (fmt == OUT_RGBA32F) return reinterpret_cast<const float4 *>(bb)[idx];
+    uint2 v = reinterpret_cast<const uint2 *>(bb)[idx];
+    return make_float4(h2f(v.x & 0xffffu), h2f(v.x >> 16), h2f(v.y & 0xffffu), h2f(v.y >> 16));
+}
+__device__ __forceinline__ float aces_film(float x) {
+    float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
+    return fminf(fmaxf(num / den, 0.0f), 1.0f);
+}
+__device__ __forceinline__ float present_srgb(float c) {
+    float sel = ceilf(c - 0.0031308f);
+    float under = 12.92f * c;
+    float over = 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * 0.41666f) - 0.055f;
+    return sel > 0.0f ? over : under;  // mix(under, over, sel) with sel in {0, 1}
+}
+__global__ __launch_bounds__(256) void present_kernel(const void *__restrict__ bb, int fmt, uint32_t bw, uint32_t bh,
+                                                      uint32_t w, uint32_t h, uint32_t *__restrict__ rgba8,
+                                                      uint32_t *__restrict__ bgra8) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)w * h) return;
+    uint32_t x = (uint32_t)(id % w), y = (uint32_t)(id / w);
+    float uvx = ((float)x + 0.5f) / (float)w, uvy = ((float)y + 0.5f) / (float)h;
+    float ux = fmaf(uvx, (float)bw, -0.5f), uy = fmaf(uvy, (float)bh, -0.5f);
+    int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy);
+    float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy);
+    int x0 = clampi(ix, 0, (int)bw - 1), x1 = clampi(ix + 1, 0, (int)bw - 1);
+    int y0 = clampi(iy, 0, (int)bh - 1), y1 = clampi(iy + 1, 0, (int)bh - 1);
+    float4 t00 = load_px(bb, fmt, (size_t)y0 * bw + x0), t10 = load_px(bb, fmt, (size_t)y0 * bw + x1);
+    float4 t01 = load_px(bb, fmt, (size_t)y1 * bw + x0), t11 = load_px(bb, fmt, (size_t)y1 * bw + x1);
+    float c[4];
+    const float a0[4] = {t00.x, t00.y, t00.z, t00.w}, a1[4] = {t10.x, t10.y, t10.z, t10.w};
+    const float b0[4] = {t01.x, t01.y, t01.z, t01.w}, b1[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float a = fmaf(fx, a1[k] - a0[k], a0[k]), b = fmaf(fx, b1[k] - b0[k], b0[k]);
+        float v = fmaf(fy, b - a, a);
+        if (k < 3) v = present_srgb(aces_film(v));
+        c[k] = floorf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+    uint32_t r = (uint32_t)c[0], g = (uint32_t)c[1], b = (uint32_t)c[2], al = (uint32_t)c[3];
+    rgba8[id] = r | (g << 8) | (b << 16) | (al << 24);
+    if (bgra8) bgra8[id] = b | (g << 8) | (r << 16) | (al << 24);
+}
+
 // Root side of the multi-GPU frame: gathered [nranks][n_slots][ts][ts] -> [H][W]
 template <int OUT>
 __global__ __launch_bounds__(256) void untile_kernel(const void *__restrict__ gathered, void *__restrict__ out,

@@ -222,19 +222,14 @@ class Context {
         return std::string("Device name: ") + name + "\nBackend: HIP\nCompute units: " + std::to_string(cus) +
                "\nScreen format: " + (render_backbuffer.format == VK_OUT_RGBA16F ? "Rgba16Float" : "Rgba32Float");
     }
-    // capture_frame (context.rs:299-302, screenshot.rs:37-77): RGBA8 rows padded to 256 B.  The
-    // reference captures the tone-mapped present target; the present pass is a later row (8f N1).
+    // Context::render (context.rs:251-297): the present pass -- backbuffer -> ACES + sRGB -> Rgba8 at the
+    // window size.  There is no surface to present to on a compute node.
+    void render() { check(ctx_, vk_present(ctx_, width, height, 0)); }
+    // capture_frame (context.rs:299-302, screenshot.rs:37-77): the presented Rgba8 frame, rows padded to 256 B
     std::pair<std::vector<uint8_t>, ImageDimentions> capture_frame() {
-        const HdrBackBuffer &bb = render_backbuffer;
-        ImageDimentions dims(bb.width, bb.height, 256);
+        ImageDimentions dims(width, height, 256);
         std::vector<uint8_t> out(dims.linear_size(), 0);
-        std::vector<float> img = read_backbuffer_f32();
-        for (uint32_t y = 0; y < dims.height; y++)
-            for (uint32_t x = 0; x < dims.width; x++)
-                for (int c = 0; c < 4; c++) {
-                    float v = std::fmin(std::fmax(img[((size_t)y * bb.width + x) * 4 + c], 0.f), 1.f);
-                    out[(size_t)y * dims.padded_bytes_per_row + x * 4 + c] = (uint8_t)(v * 255.f + 0.5f);
-                }
+        check(ctx_, vk_capture_frame(ctx_, out.data(), out.size(), nullptr, nullptr, nullptr));
         return {out, dims};
     }
     std::vector<float> read_backbuffer_f32() {
@@ -325,6 +320,7 @@ std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_fram
         demo->update(ctx);
         fc.record();
         demo->render(ctx);
+        ctx.render();  // src/lib.rs:178-182: demo.render, then context.render (present)
     }
     ctx.sync();
     if (mean_frame_ms) *mean_frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames ? frames : 1);
