@@ -89,6 +89,10 @@ int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint
 enum vk_generator { VK_GEN_FOG = 0, VK_GEN_BONSAI_STANDIN = 1 };
 int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
                        uint32_t lo, uint32_t span, int layout);
+/* XorCompute (examples/xor/xor_compute.rs:93-200): one dispatch of shaders/xor.wgsl `cs_main` at
+ * un.time = time (0 in the reference: the pass runs before the first Context::update),
+ * filling the two rgba16float storage textures (density, normals) the compute raycast reads. */
+int vk_volume_generate_xor(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, float time);
 int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes);
 
 /* GlobalUniformBinding::update, src/context/global_ubo.rs:47-49 (48-byte Uniform, :52-65). */

@@ -94,6 +94,9 @@ def lib() -> C.CDLL:
         L.vo_dispatch_optimal.argtypes = [C.c_uint32, C.c_uint32]
         L.vo_dispatch_optimal.restype = C.c_uint32
         L.vo_image_dimentions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.vo_volume_xor.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+        L.vo_sin_spec.argtypes = [C.c_float]
+        L.vo_sin_spec.restype = C.c_float
         L.vo_present.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.vo_ray_naive.argtypes = [C.POINTER(CameraUniform), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -202,3 +205,12 @@ def present(backbuffer: np.ndarray, width: int, height: int) -> np.ndarray:
     out = np.empty((height, width, 4), np.uint8)
     lib().vo_present(bb.ctypes.data, bb.shape[1], bb.shape[0], width, height, out.ctypes.data)
     return out
+
+
+def volume_xor(n, time: float = 0.0):
+    """xor.wgsl cs_main: (density, normals) as float16 [nz,ny,nx,4]."""
+    nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+    den = np.empty((nz, ny, nx, 4), np.uint16)
+    nrm = np.empty((nz, ny, nx, 4), np.uint16)
+    lib().vo_volume_xor(nx, ny, nz, time, den.ctypes.data, nrm.ctypes.data)
+    return den.view(np.float16), nrm.view(np.float16)

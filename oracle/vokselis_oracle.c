@@ -17,6 +17,7 @@
 /* ------------------------------------------------------------------------- */
 /* small vector helpers (explicit op order; no contraction)                   */
 
+static inline float smoothstepf(float e0, float e1, float x);
 static inline float vmin(float a, float b) { return fminf(a, b); }
 static inline float vmax(float a, float b) { return fmaxf(a, b); }
 
@@ -531,6 +532,110 @@ int vo_render(const vo_render_args *a) {
         }
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* xor volume generator: shaders/xor.wgsl                                     */
+
+/* sin(h) for hash(): the WGSL sin of arguments up to ~1e5 is implementation-sensitive and the
+ * hash multiplies its error by 43758, so the specification pins it: Cody-Waite
+ * reduction and minimax polynomials in f64, rounded once to f32 (== the correctly rounded f32
+ * sine except in ~1e-8 of cases, identically so wherever this op sequence runs). */
+static float sin_spec(float h) {
+    const double x = (double)h;
+    const double k = rint(x * 0.63661977236758134308);             /* 2/pi */
+    double r = fma(-k, 1.57079632673412561417e+00, x);            /* pi/2 high */
+    r = fma(-k, 6.07710050650619224932e-11, r);                   /* pi/2 low */
+    const double r2 = r * r;
+    double sp = 1.58969099521155010221e-10;                       /* sin: r + r^3 * P(r^2) */
+    sp = fma(sp, r2, -2.50507602534068634195e-08);
+    sp = fma(sp, r2, 2.75573137070700676789e-06);
+    sp = fma(sp, r2, -1.98412698298579493134e-04);
+    sp = fma(sp, r2, 8.33333333332248946124e-03);
+    sp = fma(sp, r2, -1.66666666666666324348e-01);
+    const double sn = fma(r * r2, sp, r);
+    double cp = -1.13596475577881948265e-11;                      /* cos: 1 - r^2/2 + r^4 * Q(r^2) */
+    cp = fma(cp, r2, 2.08757232129817482790e-09);
+    cp = fma(cp, r2, -2.75573143513906633035e-07);
+    cp = fma(cp, r2, 2.48015872894767294178e-05);
+    cp = fma(cp, r2, -1.38888888888741095749e-03);
+    cp = fma(cp, r2, 4.16666666666666019037e-02);
+    const double cs = fma(r2 * r2, cp, fma(-0.5, r2, 1.0));
+    const long q = (long)k & 3;
+    const double v = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+    return (float)v;
+}
+
+float vo_sin_spec(float h) { return sin_spec(h); }
+
+static inline float fractf_(float x) { return x - floorf(x); }
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; } /* WGSL mix */
+
+static float xor_hash(float h) { return fractf_(sin_spec(h) * 43758.5453123f); } /* xor.wgsl:18-20 */
+
+static float xor_noise(const float x[3]) { /* xor.wgsl:22-33 */
+    float p[3] = {floorf(x[0]), floorf(x[1]), floorf(x[2])};
+    float f[3] = {fractf_(x[0]), fractf_(x[1]), fractf_(x[2])};
+    for (int i = 0; i < 3; i++) f[i] = f[i] * f[i] * (3.0f - 2.0f * f[i]);
+    float n = p[0] + p[1] * 157.0f + 113.0f * p[2];
+    return mixf(mixf(mixf(xor_hash(n + 0.0f), xor_hash(n + 1.0f), f[0]), mixf(xor_hash(n + 157.0f), xor_hash(n + 158.0f), f[0]), f[1]),
+                mixf(mixf(xor_hash(n + 113.0f), xor_hash(n + 114.0f), f[0]), mixf(xor_hash(n + 270.0f), xor_hash(n + 271.0f), f[0]), f[1]),
+                f[2]);
+}
+
+static float xor_fbm(const float p0[3]) { /* xor.wgsl:35-44 */
+    float p[3] = {p0[0], p0[1], p0[2]};
+    float f = 0.5000f * xor_noise(p);
+    for (int i = 0; i < 3; i++) p[i] = p[i] * 2.01f;
+    f = f + 0.2500f * xor_noise(p);
+    for (int i = 0; i < 3; i++) p[i] = p[i] * 2.02f;
+    f = f + 0.1250f * xor_noise(p);
+    return f;
+}
+
+static void xor_noise_volume(const float c[3], float time, float out[4]) { /* xor.wgsl:55-61 */
+    float off[3] = {1.0f, sin_spec(time * 1.0f) * 0.1f, 21.0f};
+    float pos[3] = {(c[0] + off[0]) * 32.0f, (c[1] + off[1]) * 32.0f, (c[2] + off[2]) * 32.0f};
+    float val = xor_fbm(pos);
+    float len = sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+    float alpha = val * smoothstepf(0.5f, 0.25f, len);
+    out[0] = out[1] = out[2] = val;
+    out[3] = alpha;
+}
+
+void vo_volume_xor(uint32_t nx, uint32_t ny, uint32_t nz, float time, uint16_t *density, uint16_t *normals) {
+    const float dims[3] = {(float)nx, (float)ny, (float)nz};
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int64_t z = 0; z < (int64_t)nz; z++)
+        for (uint32_t y = 0; y < ny; y++)
+            for (uint32_t x = 0; x < nx; x++) {
+                const float id[3] = {(float)x, (float)y, (float)z};
+                float c[3];
+                for (int i = 0; i < 3; i++) c[i] = (id[i] - dims[i] / 2.0f) / dims[i]; /* xor.wgsl:72 */
+                float vol[4], a[3];
+                xor_noise_volume(c, time, vol);
+                /* gradient(coord, 0.0001): xor.wgsl:63-67 */
+                for (int k = 0; k < 3; k++) {
+                    float q[3] = {c[0], c[1], c[2]}, t4[4];
+                    q[k] = q[k] - 0.0001f;
+                    xor_noise_volume(q, time, t4);
+                    a[k] = vol[3] - t4[3];
+                }
+                float nl = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+                float nrm[3] = {a[0] / nl, a[1] / nl, a[2] / nl}; /* normalize(0) = NaN, as on a GPU */
+                float ln = sqrtf((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+                size_t o = 4 * ((size_t)x + (size_t)nx * (y + (size_t)ny * (size_t)z));
+                density[o + 0] = vo_f32_to_f16(vol[0] / 2.0f);
+                density[o + 1] = vo_f32_to_f16(vol[1] / 2.0f);
+                density[o + 2] = vo_f32_to_f16(vol[2] / 2.0f);
+                density[o + 3] = vo_f32_to_f16(vol[3]);
+                normals[o + 0] = vo_f32_to_f16(nrm[0]);
+                normals[o + 1] = vo_f32_to_f16(nrm[1]);
+                normals[o + 2] = vo_f32_to_f16(nrm[2]);
+                normals[o + 3] = vo_f32_to_f16(ln);
+            }
 }
 
 /* ------------------------------------------------------------------------- */

@@ -118,6 +118,13 @@ void vo_volume_fog_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint
                       uint32_t span, uint8_t *out);
 void vo_volume_fog_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint16_t *out);
 
+/* xor example's volume generator (next row N3): shaders/xor.wgsl:18-78 `cs_main` at un.time = t
+ * (the reference runs it once with time = 0).  Writes nx*ny*nz rgba16f texels (4 x u16)
+ * of density (vol.rgb/2, vol.a) and normals (normal, length(normal)).  hash()'s sin is specified as
+ * the correctly rounded f32 sine (evaluated in f64), which makes the volume reproducible. */
+float vo_sin_spec(float h); /* the specified sine of hash(), exposed for tests */
+void vo_volume_xor(uint32_t nx, uint32_t ny, uint32_t nz, float time, uint16_t *density, uint16_t *normals);
+
 /* Present pass (next row N1): shaders/present.wgsl:23-35,111-119 with the linear clamp-to-edge sampler of
  * src/context/present_pipeline.rs:95-104.  backbuffer: [bh][bw][4] f32 (already rounded through f16
  * by the caller when the surface is rgba16float); out: [h][w][4] u8 in RGBA order (the Rgba8Unorm

@@ -171,3 +171,22 @@ def test_present_oracle_basics(O):
     # downsampling by 2 averages 2x2 texel blocks (uv lands on texel corners)
     small = O.present(np.full((8, 8, 4), 0.18, np.float32), 4, 4)
     assert (small[..., :3] == ref(0.18)).all()
+
+
+def test_xor_generator_oracle(O):
+    """shaders/xor.wgsl restated: the hash's sine is the correctly rounded f32 sine; the volume has the
+    reference's structure (alpha only inside radius 0.5, NaN normals where the gradient vanishes)."""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-1e5, 1e5, 4000), np.arange(0.0, 400.0)]).astype(np.float32)
+    got = np.array([O.lib().vo_sin_spec(float(v)) for v in x], np.float32)
+    assert (got == np.sin(x.astype(np.float64)).astype(np.float32)).all()
+    den, nrm = O.volume_xor(24, 0.0)
+    a = den[..., 3].astype(np.float32)
+    z, y, xx = np.meshgrid(*[(np.arange(24) - 12) / 24.0] * 3, indexing="ij")
+    r = np.sqrt(xx * xx + y * y + z * z)
+    assert (a[r > 0.5] == 0).all() and (a[r < 0.2] > 0).all()
+    assert (den[..., 0] == den[..., 1]).all() and (den[..., 0] == den[..., 2]).all()
+    n3 = nrm[..., :3].astype(np.float32)
+    assert np.isnan(n3[r > 0.51]).all()                     # normalize(0): the reference stores NaN there too
+    ok = ~np.isnan(n3).any(axis=-1)
+    assert np.abs(np.linalg.norm(n3[ok], axis=-1) - 1).max() < 2e-3

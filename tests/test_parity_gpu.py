@@ -376,3 +376,47 @@ def test_present_pass_and_capture_frame(V, O):
                 assert (got[..., 3] == 255).all()
             finally:
                 ctx.close()
+
+
+def test_xor_generator_and_example(V, O, tmp_path):
+    """Next rows N3/N4: shaders/xor.wgsl on the device is bit-identical to the oracle's generator (the
+    hash's sine is specified), and the xor example (generator + compute raycast, SinglePass and Tile
+    modes) reproduces the oracle's frame."""
+    import os
+    import subprocess
+
+    import __graft_entry__ as g
+
+    n, W, H = 64, 320, 180
+    den, nrm = O.volume_xor(n, 0.0)
+    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix()
+    ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
+    assert (rsteps > 0).mean() > 0.1
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture.generate_xor(ctx, (n, n, n), 0.0)
+        ctx.set_camera_blob(cam)
+        V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, flags=V.RENDER_COUNT).record(ctx)
+        img, steps = ctx.read_backbuffer(), ctx.read_steps()
+        assert (steps == rsteps).all()           # identical volumes -> identical trip counts
+        assert np.abs(img - ref).max() <= TOL
+        # device-generated == host-uploaded oracle volume, bit for bit
+        V.VolumeTexture(ctx, den, nrm)
+        V.RaycastPipeline(V.MODE_COMPUTE_NEAREST).record(ctx)
+        assert (ctx.read_backbuffer() == img).all()
+    finally:
+        ctx.close()
+    # the compiled example, both modes of examples/xor/main.rs:14-18
+    g.build_host()
+    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "xor")
+    ref16 = O.rgba32f_to_rgba16f(ref).view(np.float16).astype(np.float32)
+    want = O.present(ref16, W, H)[..., :3].astype(np.int32)
+    for mode in ("single", "tile"):
+        ppm = tmp_path / f"xor_{mode}.ppm"
+        r = subprocess.run([exe, "--frames", "2", "--size", f"{W}x{H}", "--volume", str(n), "--mode", mode, "--ppm", str(ppm)],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        data = ppm.read_bytes().split(b"\n255\n", 1)[1]
+        got = np.frombuffer(data, np.uint8).reshape(H, W, 3).astype(np.int32)
+        d = np.abs(got - want)
+        assert d.max() <= 2 and (d == 0).mean() > 0.99, (mode, d.max(), (d == 0).mean())

@@ -31,6 +31,7 @@ SYMBOLS = {
     "vk_volume_upload": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
     "vk_volume_upload_device": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
     "vk_volume_generate": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, C.c_int, _u32, _u32, _u32, C.c_int]),
+    "vk_volume_generate_xor": (C.c_int, [_vp, _u32, _u32, _u32, _f32]),
     "vk_volume_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
     "vk_set_uniform": (C.c_int, [_vp, _vp]),
     "vk_set_camera": (C.c_int, [_vp, _vp]),

@@ -288,6 +288,15 @@ class VolumeTexture:
         return cls.generate(ctx, N.GEN_FOG, dims, fmt, seed, lo, span, layout)
 
     @classmethod
+    def generate_xor(cls, ctx: Context, dims=(256, 256, 256), time: float = 0.0) -> "VolumeTexture":
+        """XorCompute (examples/xor/xor_compute.rs): shaders/xor.wgsl cs_main -> density + normals rgba16f."""
+        nx, ny, nz = dims
+        N.check(ctx.handle, N.lib().vk_volume_generate_xor(ctx.handle, nx, ny, nz, time))
+        self = cls.__new__(cls)
+        self.dims, self.format = (nx, ny, nz), N.FMT_RGBA16F_PAIR
+        return self
+
+    @classmethod
     def generate_standin(cls, ctx: Context, dims=(256, 256, 256), seed=0x5EED0001, layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
         return cls.generate(ctx, N.GEN_BONSAI_STANDIN, dims, N.FMT_R8_UNORM, seed, 0, 1, layout)
 

@@ -344,6 +344,24 @@ int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t
     return build_from_dense(ctx, d, nullptr, true, nx, ny, nz, format, layout);
 }
 
+int vk_volume_generate_xor(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, float time) {
+    int dummy = 0;
+    int rc = check_volume_args(ctx, &dummy, &dummy, nx, ny, nz, VK_FMT_RGBA16F_PAIR, VK_LAYOUT_LINEAR);
+    if (rc) return rc;
+    if (!std::isfinite(time)) return fail(ctx, VK_ERR_INVALID, "time must be finite");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_vox = (size_t)nx * ny * nz;
+    if ((n_vox + 255) / 256 >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large");
+    void *d = nullptr, *d2 = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, n_vox * 8));
+    hipError_t e = hipMalloc(&d2, n_vox * 8);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, VK_ERR_OOM, std::string("xor normals: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(xor_generate_kernel, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, ctx->stream, (uint2 *)d, (uint2 *)d2, nx, ny, nz, time);
+    e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(d); (void)hipFree(d2); return fail(ctx, VK_ERR_HIP, std::string("xor generator launch: ") + hipGetErrorString(e)); }
+    return build_from_dense(ctx, d, d2, true, nx, ny, nz, VK_FMT_RGBA16F_PAIR, VK_LAYOUT_LINEAR);
+}
+
 int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes) {
     if (!ctx) return VK_ERR_INVALID;
     if (ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "no volume uploaded");

@@ -674,6 +674,85 @@ __global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, u
     }
 }
 
+// ---- xor example's volume generator (next row N3): shaders/xor.wgsl:18-78 --------------------
+// cs_main for every voxel: fbm value noise (3 octaves x 8 sin-hashes) and its finite-difference
+// gradient (3 more evaluations).  ALU-bound: 96 hashes per voxel.  hash()'s sine is the specified
+// one (f64 Cody-Waite + minimax polynomial, rounded once to f32), so the volume is reproducible.
+__device__ __forceinline__ float sin_spec(float h) {
+    const double x = (double)h;
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double r2 = r * r;
+    double sp = 1.58969099521155010221e-10;
+    sp = fma(sp, r2, -2.50507602534068634195e-08);
+    sp = fma(sp, r2, 2.75573137070700676789e-06);
+    sp = fma(sp, r2, -1.98412698298579493134e-04);
+    sp = fma(sp, r2, 8.33333333332248946124e-03);
+    sp = fma(sp, r2, -1.66666666666666324348e-01);
+    const double sn = fma(r * r2, sp, r);
+    double cp = -1.13596475577881948265e-11;
+    cp = fma(cp, r2, 2.08757232129817482790e-09);
+    cp = fma(cp, r2, -2.75573143513906633035e-07);
+    cp = fma(cp, r2, 2.48015872894767294178e-05);
+    cp = fma(cp, r2, -1.38888888888741095749e-03);
+    cp = fma(cp, r2, 4.16666666666666019037e-02);
+    const double cs = fma(r2 * r2, cp, fma(-0.5, r2, 1.0));
+    const long q = (long)k & 3;
+    const double v = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+    return (float)v;
+}
+__device__ __forceinline__ float xor_fract(float x) { return x - floorf(x); }
+__device__ __forceinline__ float xor_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float xor_hash(float h) { return xor_fract(sin_spec(h) * 43758.5453123f); }
+__device__ float xor_noise(float x0, float x1, float x2) {
+    const float p0 = floorf(x0), p1 = floorf(x1), p2 = floorf(x2);
+    float f0 = xor_fract(x0), f1 = xor_fract(x1), f2 = xor_fract(x2);
+    f0 = f0 * f0 * (3.0f - 2.0f * f0); f1 = f1 * f1 * (3.0f - 2.0f * f1); f2 = f2 * f2 * (3.0f - 2.0f * f2);
+    const float n = p0 + p1 * 157.0f + 113.0f * p2;
+    return xor_mix(xor_mix(xor_mix(xor_hash(n + 0.0f), xor_hash(n + 1.0f), f0), xor_mix(xor_hash(n + 157.0f), xor_hash(n + 158.0f), f0), f1),
+                   xor_mix(xor_mix(xor_hash(n + 113.0f), xor_hash(n + 114.0f), f0), xor_mix(xor_hash(n + 270.0f), xor_hash(n + 271.0f), f0), f1),
+                   f2);
+}
+__device__ float xor_fbm(float p0, float p1, float p2) {
+    float f = 0.5000f * xor_noise(p0, p1, p2);
+    p0 = p0 * 2.01f; p1 = p1 * 2.01f; p2 = p2 * 2.01f;
+    f = f + 0.2500f * xor_noise(p0, p1, p2);
+    p0 = p0 * 2.02f; p1 = p1 * 2.02f; p2 = p2 * 2.02f;
+    f = f + 0.1250f * xor_noise(p0, p1, p2);
+    return f;
+}
+__device__ __forceinline__ void xor_noise_volume(float c0, float c1, float c2, float off1, float &val, float &alpha) {
+    val = xor_fbm((c0 + 1.0f) * 32.0f, (c1 + off1) * 32.0f, (c2 + 21.0f) * 32.0f);
+    const float len = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    alpha = val * smoothstepf(0.5f, 0.25f, len);
+}
+__global__ __launch_bounds__(256) void xor_generate_kernel(uint2 *__restrict__ density, uint2 *__restrict__ normals,
+                                                           uint32_t nx, uint32_t ny, uint32_t nz, float time) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)nx * ny * nz) return;
+    const uint32_t x = (uint32_t)(id % nx);
+    const uint64_t rest = id / nx;
+    const uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
+    const float d0 = (float)nx, d1 = (float)ny, d2 = (float)nz;
+    const float c0 = ((float)x - d0 / 2.0f) / d0, c1 = ((float)y - d1 / 2.0f) / d1, c2 = ((float)z - d2 / 2.0f) / d2;
+    const float off1 = sin_spec(time * 1.0f) * 0.1f;
+    float val, alpha, v1, a0, a1, a2;
+    xor_noise_volume(c0, c1, c2, off1, val, alpha);
+    xor_noise_volume(c0 - 0.0001f, c1, c2, off1, v1, a0);
+    xor_noise_volume(c0, c1 - 0.0001f, c2, off1, v1, a1);
+    xor_noise_volume(c0, c1, c2 - 0.0001f, off1, v1, a2);
+    const float g0 = alpha - a0, g1 = alpha - a1, g2 = alpha - a2;
+    const float nl = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+    const float n0 = g0 / nl, n1 = g1 / nl, n2 = g2 / nl;  // normalize(0) = NaN, as on any GPU
+    const float ln = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
+    union { _Float16 h[4]; uint2 u; } dv, nv;
+    dv.h[0] = (_Float16)(val / 2.0f); dv.h[1] = dv.h[0]; dv.h[2] = dv.h[0]; dv.h[3] = (_Float16)alpha;
+    nv.h[0] = (_Float16)n0; nv.h[1] = (_Float16)n1; nv.h[2] = (_Float16)n2; nv.h[3] = (_Float16)ln;
+    density[id] = dv.u;
+    normals[id] = nv.u;
+}
+
 template <int OUT>
 __global__ __launch_bounds__(256) void clear_kernel(void *out, uint64_t n_px) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -284,6 +284,12 @@ class VolumeTexture {
         return VolumeTexture(nx, ny, nz, fmt);
     }
 
+    // XorCompute::new + record (examples/xor/xor_compute.rs): density + normals from shaders/xor.wgsl
+    static VolumeTexture generate_xor(Context &ctx, uint32_t nx = 256, uint32_t ny = 256, uint32_t nz = 256, float time = 0.f) {
+        check(ctx.handle(), vk_volume_generate_xor(ctx.handle(), nx, ny, nz, time));
+        return VolumeTexture(nx, ny, nz, VK_FMT_RGBA16F_PAIR);
+    }
+
   private:
     VolumeTexture(uint32_t a, uint32_t b, uint32_t c, int f) : nx(a), ny(b), nz(c), format(f) {}
 };
