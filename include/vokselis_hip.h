@@ -129,8 +129,15 @@ int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank
  * position q of the order belongs to rank q % nranks, slot q / nranks.  order_out[q] = row-major
  * tile id; identical on every rank for identical camera, volume dims and backbuffer size. */
 int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *order_out, uint32_t n_tiles);
-/* Root side: scatter the gathered [nranks][n_slots][ts][ts] pixels into the backbuffer. */
-int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks);
+/* Only the leading n_active_tiles positions of the order can hold non-clear pixels (tiles touching the
+ * cube's screen rectangle); vk_render_partition marches just those, so a rank's compact buffer is
+ * meaningful in its first n_active_slots = ceil(n_active_tiles / nranks) slots and only those need
+ * to be gathered.  Camera-dependent; identical on every rank. */
+int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nranks, uint32_t *n_active_tiles,
+                        uint32_t *n_active_slots);
+/* Root side: scatter the gathered [nranks][slot_stride][ts][ts] pixels into the backbuffer; tiles beyond
+ * the active ones are cleared to (0,0,0,1). */
+int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride);
 
 /* ---- present + screenshot ---------------------------------------- */
 /* Context::render's present pass (src/context.rs:251-297, shaders/present.wgsl:23-35,111-119): bilinear

@@ -38,7 +38,7 @@ def _worker(rank, world, port, W, H, ts, q):
                 full, _, _ = O.render(cam, vol, W, H, dt_scale=dt, tile=(x0, y0, ts, ts), want_counts=False)
                 tile = full[y0:y0 + ts, x0:x0 + ts]
                 buf[j, :tile.shape[0], :tile.shape[1]] = tile
-            works.append(fg.start(k))
+            works.append(fg.start(k, fg.slots if k == 0 else None))
         for w in works:
             w.wait()
         if rank == 0:

@@ -169,9 +169,13 @@ def test_partition_untile_equals_frame(V, O):
             ctx.sync()
             order = ctx.partition_order(ts)
             assert sorted(order.tolist()) == list(range(len(order)))  # a permutation of the tiles
-            host = D.untile_reference(gathered.cpu().numpy(), W, H, ts, order)
+            n_active, n_slots_active = ctx.partition_active(ts, world)
+            assert 0 < n_active < len(order) and n_slots_active == -(-n_active // world)
+            g_host = gathered.cpu().numpy()
+            g_host[:, n_slots_active:] = np.nan  # slots beyond the active ones are never read
+            host = D.untile_reference(g_host, W, H, ts, order, n_active)
             assert np.abs(host - ref).max() <= TOL
-            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world))
+            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world, slots))
             img = ctx.read_backbuffer()
             assert (img == host).all()
         finally:

@@ -200,6 +200,13 @@ class Context:
         N.check(self._h, N.lib().vk_capture_frame(self._h, buf.ctypes.data, buf.size, None, None, None))
         return buf.tobytes(), dims
 
+    def partition_active(self, tile_size: int, nranks: int = 1, mode: int = N.MODE_NAIVE_TRILINEAR):
+        """(active tiles, active slots per rank): only those leading positions of the order are marched /
+        gathered; the rest of the frame is clear colour."""
+        a, b = C.c_uint32(), C.c_uint32()
+        N.check(self._h, N.lib().vk_partition_active(self._h, mode, tile_size, nranks, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def partition_order(self, tile_size: int, mode: int = N.MODE_NAIVE_TRILINEAR) -> np.ndarray:
         """Heaviest-first tile order of the frame partition (position -> row-major tile id)."""
         bb = self.render_backbuffer

@@ -46,6 +46,7 @@ struct vk_ctx {
 
     // heaviest-first tile order (launch-order heuristic; see tile_order_update)
     std::vector<uint32_t> order, order_pos;
+    uint32_t order_active = 0;  // leading positions of `order` whose tiles can contain non-clear pixels
     std::vector<unsigned char> order_key;
     unsigned long long *trace = nullptr;
     size_t trace_blocks = 0;
@@ -454,6 +455,29 @@ static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     else { if (safe) launch_naive<VOL, false, true>(ctx, L, V, grid, count); else launch_naive<VOL, false, false>(ctx, L, V, grid, count); }
 }
 
+// Screen-space bounding rectangle of the unit cube (NAIVE mode): the 8 corners projected with
+// proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
+// Pixels outside [x0,x1) x [y0,y1) cannot hit the box.
+static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) {
+    r[0] = 0; r[1] = 0; r[2] = (int32_t)ctx->width; r[3] = (int32_t)ctx->height;
+    if (mode != VK_MODE_NAIVE_TRILINEAR) return;
+    const float *pv = ctx->camera + 4;
+    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+    for (int c = 0; c < 8; c++) {
+        const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
+        const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
+        const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
+        if (!(cw > 1e-6)) return;
+        const double sx = (cx / cw * 0.5 + 0.5) * ctx->width, sy = (0.5 - cy / cw * 0.5) * ctx->height;
+        x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
+    }
+    if (!(std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1))) return;
+    r[0] = (int32_t)std::max(0.0, std::floor(x0) - 2.0);
+    r[1] = (int32_t)std::max(0.0, std::floor(y0) - 2.0);
+    r[2] = (int32_t)std::min((double)ctx->width, std::ceil(x1) + 2.0);
+    r[3] = (int32_t)std::min((double)ctx->height, std::ceil(y1) + 2.0);
+}
+
 // Tiles are dealt to the launch (and, at N > 1, to the ranks) heaviest first.  The frame is ~70 %
 // empty and a dense ray ends after 2 steps while a grazing one takes 513, so with ~10 working waves
 // per SIMD the kernel's tail is set by whichever heavy tiles start last; starting them first (and
@@ -514,7 +538,24 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
         }
     ctx->order.resize(n);
     for (size_t t = 0; t < n; t++) ctx->order[t] = (uint32_t)t;
-    std::stable_sort(ctx->order.begin(), ctx->order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    // tiles that do not touch the cube's screen rectangle hold only clear-colour pixels: they sort last and
+    // are "inactive" -- never marched, never gathered (the root clears them in vk_untile)
+    int32_t cr[4];
+    cull_rect(ctx, mode, cr);
+    std::vector<unsigned char> active(n, 1);
+    uint32_t n_active = 0;
+    for (uint32_t j = 0; j < ty; j++)
+        for (uint32_t i = 0; i < tx; i++) {
+            const int64_t x0 = (int64_t)ox + (int64_t)i * ts, y0 = (int64_t)oy + (int64_t)j * ts;
+            const bool a = !(x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3]);
+            active[(size_t)j * tx + i] = a;
+            n_active += a;
+        }
+    std::stable_sort(ctx->order.begin(), ctx->order.end(), [&](uint32_t a, uint32_t b) {
+        if (active[a] != active[b]) return active[a] > active[b];
+        return cost[a] > cost[b];
+    });
+    ctx->order_active = n_active;
     ctx->order_pos.resize(n);
     for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
     if (ctx->d_order_cap < n) {
@@ -575,27 +616,10 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.ts = ts;
     L.tiles_x = (rw + ts - 1) / ts;
     L.tiles_y = (rh + ts - 1) / ts;
-    // screen-space bounding rectangle of the unit cube (NAIVE mode): project the 8 corners with
-    // proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
-    L.cull_x0 = 0; L.cull_y0 = 0; L.cull_x1 = (int32_t)ctx->width; L.cull_y1 = (int32_t)ctx->height;
-    if (mode == VK_MODE_NAIVE_TRILINEAR) {
-        const float *pv = ctx->camera + 4;
-        double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
-        bool ok = true;
-        for (int c = 0; c < 8 && ok; c++) {
-            const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
-            const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
-            const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
-            if (!(cw > 1e-6)) { ok = false; break; }
-            const double sx = (cx / cw * 0.5 + 0.5) * ctx->width, sy = (0.5 - cy / cw * 0.5) * ctx->height;
-            x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
-        }
-        if (ok && std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1)) {
-            L.cull_x0 = (int32_t)std::max(0.0, std::floor(x0) - 2.0);
-            L.cull_y0 = (int32_t)std::max(0.0, std::floor(y0) - 2.0);
-            L.cull_x1 = (int32_t)std::min((double)ctx->width, std::ceil(x1) + 2.0);
-            L.cull_y1 = (int32_t)std::min((double)ctx->height, std::ceil(y1) + 2.0);
-        }
+    {
+        int32_t cr[4];
+        cull_rect(ctx, mode, cr);
+        L.cull_x0 = cr[0]; L.cull_y0 = cr[1]; L.cull_x1 = cr[2]; L.cull_y1 = cr[3];
     }
     L.rank = rank; L.nranks = nranks;
     {
@@ -603,8 +627,11 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         if (orc) return orc;
         L.tile_order = ctx->d_order;
     }
-    const uint64_t tiles = (uint64_t)L.tiles_x * L.tiles_y;
+    // a partition (compact output) covers only the active tiles; a plain render covers the whole region
+    const uint64_t tiles = compact_out ? (uint64_t)ctx->order_active : (uint64_t)L.tiles_x * L.tiles_y;
     const uint64_t slots = (tiles + nranks - 1) / nranks;
+    L.n_tiles_launch = (uint32_t)tiles;
+    if (tiles == 0) return VK_OK;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
     const uint64_t n_blocks = slots * per_tile;
     if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large");
@@ -688,6 +715,18 @@ int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank
     return render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
 }
 
+int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nranks, uint32_t *n_active_tiles, uint32_t *n_active_slots) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->backbuffer || !ctx->have_camera || ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "vk_partition_active: needs volume, camera and backbuffer");
+    if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "bad tile size / nranks");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int orc = tile_order_update(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+    if (orc) return orc;
+    if (n_active_tiles) *n_active_tiles = ctx->order_active;
+    if (n_active_slots) *n_active_slots = (ctx->order_active + nranks - 1) / nranks;
+    return VK_OK;
+}
+
 int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *order_out, uint32_t n_tiles) {
     if (!ctx || !order_out) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: NULL argument");
     if (!ctx->backbuffer || !ctx->have_camera || ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: needs volume, camera and backbuffer");
@@ -700,11 +739,10 @@ int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *orde
     return VK_OK;
 }
 
-int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks) {
+int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride) {
     if (!ctx || !gathered) return fail(ctx, VK_ERR_INVALID, "vk_untile: NULL argument");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
-    uint32_t n_slots = 0;
-    if (vk_partition_slots(ctx->width, ctx->height, tile_size, nranks, &n_slots)) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
+    if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "vk_untile: no camera (the tile order follows the camera)");
     {
@@ -714,10 +752,11 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
+    const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos, ctx->order_active);
     else
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos, ctx->order_active);
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
 }

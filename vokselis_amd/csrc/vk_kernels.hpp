@@ -58,6 +58,7 @@ struct LaunchDesc {
     uint32_t rw, rh;     // region size
     uint32_t ts;         // partition tile edge, multiple of 8
     uint32_t tiles_x, tiles_y;
+    uint32_t n_tiles_launch;  // leading positions of the order this launch covers
     uint32_t rank, nranks;
     uint32_t n_blocks;   // logical 8x8 blocks of this launch
     uint32_t compact;    // 1: output is [slot][ts][ts], 0: [H][W]
@@ -94,7 +95,7 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, uint32_t lb, 
     uint32_t slot = lb / per_tile, sub = lb - slot * per_tile;
     uint32_t pos = L.rank + slot * L.nranks;  // position in the heaviest-first order
     const uint32_t n_tiles = L.tiles_x * L.tiles_y;
-    uint32_t tile = pos < n_tiles ? L.tile_order[pos] : n_tiles;
+    uint32_t tile = pos < L.n_tiles_launch ? L.tile_order[pos] : n_tiles;
     uint32_t tty = tile / L.tiles_x, ttx = tile - tty * L.tiles_x;
     uint32_t sy = sub / sps, sx = sub - sy * sps;
     uint32_t lx = sx * 8 + (lane & 7u), ly = sy * 8 + (lane >> 3);  // inside the tile
@@ -813,11 +814,15 @@ template <int OUT>
 __global__ __launch_bounds__(256) void untile_kernel(const void *__restrict__ gathered, void *__restrict__ out,
                                                      uint32_t W, uint32_t H, uint32_t ts, uint32_t tiles_x,
                                                      uint32_t nranks, uint32_t n_slots,
-                                                     const uint32_t *__restrict__ tile_pos) {
+                                                     const uint32_t *__restrict__ tile_pos, uint32_t n_active) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (uint64_t)W * H) return;
     uint32_t x = (uint32_t)(id % W), y = (uint32_t)(id / W);
     uint32_t pos = tile_pos[(y / ts) * tiles_x + (x / ts)];  // tile id -> position in the order
+    if (pos >= n_active) {  // tile outside the cube's screen rectangle: never marched, never gathered
+        store_pixel<OUT>(out, id, 0.0f, 0.0f, 0.0f, 1.0f);
+        return;
+    }
     uint32_t rank = pos % nranks, slot = pos / nranks;
     size_t src = (((size_t)rank * n_slots + slot) * ts + (y % ts)) * ts + (x % ts);
     if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];

@@ -64,11 +64,13 @@ class FrameGather:
         if self.rank == root:
             self.gathered = [torch.zeros((self.world,) + shape, dtype=channels_dtype, device=device) for _ in range(2)]
 
-    def start(self, k: int):
-        """Launch the gather of compact[k % 2] (async); returns the work handle."""
-        buf = self.compact[k % 2]
+    def start(self, k: int, n_slots: int | None = None):
+        """Launch the gather of the first `n_slots` slots of compact[k % 2] (async); returns the work
+        handle.  Slots beyond the active ones hold nothing worth moving (`Context.partition_active`)."""
+        n = self.slots if n_slots is None else min(n_slots, self.slots)
+        buf = self.compact[k % 2][:n]
         if self.rank == self.root:
-            out = list(self.gathered[k % 2].unbind(0))
+            out = [self.gathered[k % 2][r, :n] for r in range(self.world)]
             return self.dist.gather(buf, gather_list=out, dst=self.root, group=self.group, async_op=True)
         return self.dist.gather(buf, dst=self.root, group=self.group, async_op=True)
 
@@ -96,7 +98,12 @@ class TileParallelRenderer:
         """Frame k: march this rank's tiles, start their gather; finish frame k-1 on the root."""
         fg = self.fg
         self.pipe.record_partition(self.ctx, fg.ts, fg.rank, fg.world, fg.compact[k % 2].data_ptr())
-        work = fg.start(k)
+        _, n_slots = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)  # cached per camera in the library
+        if n_slots == 0:
+            self._finish_pending()
+            self._pending = (k, None)
+            return
+        work = fg.start(k, n_slots)
         self._finish_pending()
         self._pending = (k, work)
 
@@ -104,18 +111,20 @@ class TileParallelRenderer:
         if self._pending is None:
             return
         k, work = self._pending
-        work.wait()  # orders the current stream after the collective
+        if work is not None:
+            work.wait()  # orders the current stream after the collective
         if self.is_root:
             N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, self.fg.gathered[k % 2].data_ptr(), self.fg.ts,
-                                                      self.fg.world))
+                                                      self.fg.world, self.fg.slots))
         self._pending = None
 
     def flush(self):
         self._finish_pending()
 
 
-def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None) -> np.ndarray:
-    """numpy statement of vk_untile: [world, n_slots, ts, ts, C] -> [H, W, C]."""
+def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None, n_active=None) -> np.ndarray:
+    """numpy statement of vk_untile: [world, n_slots, ts, ts, C] -> [H, W, C]; tiles at positions
+    >= n_active of the order are clear colour (0,0,0,1)."""
     world = gathered.shape[0]
     tx, ty = tiles_xy(width, height, tile_size)
     pos = np.arange(tx * ty) if order is None else np.argsort(np.asarray(order))  # tile id -> position
@@ -124,5 +133,8 @@ def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: i
         for x0 in range(0, width, tile_size):
             q = int(pos[(y0 // tile_size) * tx + x0 // tile_size])
             h, w = min(tile_size, height - y0), min(tile_size, width - x0)
-            out[y0:y0 + h, x0:x0 + w] = gathered[q % world, q // world, :h, :w]
+            if n_active is not None and q >= n_active:
+                out[y0:y0 + h, x0:x0 + w] = [0, 0, 0, 1][: out.shape[-1]]
+            else:
+                out[y0:y0 + h, x0:x0 + w] = gathered[q % world, q // world, :h, :w]
     return out
