@@ -254,11 +254,11 @@ def main():
             extras = {}
             it = 50
             p_ns = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_NO_SKIP)
-            p_sk = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=0)
+            p_sk = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_FORCE_SKIP)
             for name, mk in (("standin", None), ("fog", lambda: V.VolumeTexture.generate_fog(ctx, (N_VOL,) * 3, layout=layout))):
                 if mk is not None:
                     mk()
-                for mode, p, fl in (("noskip", p_ns, V.RENDER_NO_SKIP), ("skip", p_sk, 0)):
+                for mode, p, fl in (("noskip", p_ns, V.RENDER_NO_SKIP), ("skip", p_sk, V.RENDER_FORCE_SKIP)):
                     sr, ss = count_steps(ctx, V, fl)
                     ms = time_launches(ctx, p, it)
                     gb = (ss * B_STEP + W * H * B_RAY) / (ms * 1e-3) / 1e9

@@ -50,13 +50,16 @@ enum vk_layout {
     VK_LAYOUT_AUTO = 0,
     VK_LAYOUT_LINEAR = 1, /* x-fastest as uploaded; 8 scalar taps per sample (validation kernel) */
     VK_LAYOUT_PACKED = 2, /* 4^3-bricked cells, each holding its 8 trilinear taps (+ skip map) */
-    VK_LAYOUT_PACKED_PAIRS = 3 /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
+    VK_LAYOUT_PACKED_PAIRS = 3, /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
+    VK_LAYOUT_BRICKED = 4 /* dense 8^3 bricks + 1-voxel apron (9^3): 1.42x the dense bytes, 8 taps from one
+                             brick; for volumes far larger than the caches (no skip map) */
 };
 
 enum vk_render_flags {
     VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
     VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
-    VK_RENDER_SAFE = 4      /* force the clamped / 64-bit-offset kernel variant */
+    VK_RENDER_SAFE = 4,     /* force the clamped / 64-bit-offset kernel variant */
+    VK_RENDER_FORCE_SKIP = 8 /* skip even when < 10 % of the cells are transparent (default: auto) */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */
@@ -93,6 +96,8 @@ int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t
  * un.time = time (0 in the reference: the pass runs before the first Context::update),
  * filling the two rgba16float storage textures (density, normals) the compute raycast reads. */
 int vk_volume_generate_xor(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, float time);
+/* Share of the cells that are exactly transparent under the transfer function (packed layouts). */
+int vk_volume_empty_fraction(vk_ctx *ctx, double *fraction);
 int vk_volume_info(vk_ctx *ctx, uint32_t dims[3], int *format, int *layout, size_t *device_bytes);
 
 /* GlobalUniformBinding::update, src/context/global_ubo.rs:47-49 (48-byte Uniform, :52-65). */

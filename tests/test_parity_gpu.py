@@ -32,6 +32,8 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
         V.VolumeTexture(ctx, vol, vol2, layout=V.LAYOUT_AUTO if layout is None else layout)
         ctx.set_camera_blob(cam_blob)
         ctx.reset_step_counts()
+        if not (flags & V.RENDER_NO_SKIP):
+            flags |= V.RENDER_FORCE_SKIP  # exercise the skip path whatever the volume's empty share
         pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR if mode is None else mode, dt_scale=dt,
                                  flags=flags | (V.RENDER_COUNT if want_steps else 0))
         pipe.record(ctx, tile)
@@ -44,7 +46,7 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
 
 
 def layouts(V):
-    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR}
+    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -60,7 +62,7 @@ def test_golden_vectors_every_layout(V, golden, cameras, golden_volumes):
             assert np.abs(img - g[key + "__rgba"]).max() <= TOL, (key, lname)
             assert (steps == g[key + "__steps"]).all(), (key, lname)
             assert s_ref == int(g[key + "__steps"].astype(np.int64).sum())
-            if lname != "LIN":  # exact empty-space skipping fetches taps only where a tap can contribute
+            if lname in ("P8", "P16"):  # exact empty-space skipping fetches taps only where a tap can contribute
                 assert s_samp == int(g[key + "__sampled"].astype(np.int64).sum()), (key, lname)
 
 
@@ -185,7 +187,7 @@ def test_partition_untile_equals_frame(V, O):
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)
-    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
+    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR, V.LAYOUT_BRICKED):
         img, steps, _ = gpu_render(V, cameras["bonsai_1x1"], vol, 64, 64, dt=0.5, layout=lay)
         assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
     # a dense-core f16 volume exercises the early-out and the skip map's 0.1 threshold
@@ -243,6 +245,8 @@ def test_cameras_dims_and_dt(V, O):
                 assert np.abs(img - ref).max() <= TOL, (dims, lay, fl)
                 assert (steps == rsteps).all(), (dims, lay, fl)
                 assert s_samp == int(rsamp.sum())
+        img, steps, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=V.LAYOUT_BRICKED)  # 9^3 dense bricks
+        assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dims, "bricked")
 
 
 def test_compute_nearest_mode(V, O, golden, cameras):
@@ -424,3 +428,30 @@ def test_xor_generator_and_example(V, O, tmp_path):
         got = np.frombuffer(data, np.uint8).reshape(H, W, 3).astype(np.int32)
         d = np.abs(got - want)
         assert d.max() <= 2 and (d == 0).mean() > 0.99, (mode, d.max(), (d == 0).mean())
+
+
+def test_large_volume_layouts_agree(V, O):
+    """Beyond the cache-resident sizes: a 640^3 u8 fog (262 M voxels) rendered through three independent
+    layouts/kernels (9^3 dense bricks, 8-B cells, dense linear) gives bitwise-identical frames and trip
+    counts, and a tile of it matches the CPU oracle."""
+    n, W, H = 640, 960, 540
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
+    imgs, steps = {}, {}
+    for name, lay in (("b9", V.LAYOUT_BRICKED), ("p8", V.LAYOUT_PACKED), ("lin", V.LAYOUT_LINEAR)):
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture.generate_fog(ctx, (n, n, n), seed=0x5EED0005, layout=lay)
+            ctx.set_camera_blob(cam)
+            V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT | V.RENDER_FORCE_SKIP).record(ctx)
+            imgs[name], steps[name] = ctx.read_backbuffer(), ctx.read_steps()
+        finally:
+            ctx.close()
+    for other in ("p8", "lin"):
+        assert (imgs["b9"].view(np.uint32) == imgs[other].view(np.uint32)).all(), other
+        assert (steps["b9"] == steps[other]).all(), other
+    assert steps["b9"].max() == 2 * n + 1  # dt_scale 0.5: <= 2n+1 iterations (SURVEY F7)
+    tile = (448, 238, 64, 64)
+    ref, rsteps, _ = O.render(cam, O.volume_fog_u8(n, seed=0x5EED0005), W, H, dt_scale=0.5, tile=tile)
+    ys, xs = slice(tile[1], tile[1] + 64), slice(tile[0], tile[0] + 64)
+    assert (steps["b9"][ys, xs] == rsteps[ys, xs]).all() and rsteps[ys, xs].min() > 0
+    assert np.abs(imgs["b9"][ys, xs] - ref[ys, xs]).max() <= TOL

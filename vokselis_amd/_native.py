@@ -14,8 +14,8 @@ VK_OK = 0
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
 MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS = 0, 1, 2, 3
-RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE = 1, 2, 4
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED = 0, 1, 2, 3, 4
+RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 GEN_FOG, GEN_BONSAI_STANDIN = 0, 1
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
@@ -32,6 +32,7 @@ SYMBOLS = {
     "vk_volume_upload_device": (C.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, C.c_int, C.c_int]),
     "vk_volume_generate": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, C.c_int, _u32, _u32, _u32, C.c_int]),
     "vk_volume_generate_xor": (C.c_int, [_vp, _u32, _u32, _u32, _f32]),
+    "vk_volume_empty_fraction": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "vk_volume_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)]),
     "vk_set_uniform": (C.c_int, [_vp, _vp]),
     "vk_set_camera": (C.c_int, [_vp, _vp]),

@@ -30,7 +30,11 @@ constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
 
 // P8: 8 u8 taps (8 B).  P16: u8 volume as 4 x (tap, delta = next_x_tap - tap) f16 pairs (16 B).
 // PF16: f16 volume, 8 f16 taps (16 B).
-enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4 };
+// B9U8 / B9F16: dense voxels in 8^3 bricks stored with a one-voxel apron on the low side (9^3 = 729
+// voxels, clamp-to-edge baked in): brick b holds voxels [8b-1, 8b+7] per axis, so the 8 taps of any
+// sample come from ONE brick at fixed local offsets (+1, +9, +81).  1.42x the dense bytes instead
+// of 8-16x: the layout for volumes far larger than the caches.
+enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6 };
 enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 
 struct VolumeDesc {
@@ -230,7 +234,8 @@ __device__ __forceinline__ bool wave_leader() {
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
-    static_assert(PACKED || (!SKIP && SAFE), "linear layout: validation kernel only");
+    constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
+    static_assert(PACKED || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
@@ -360,6 +365,30 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
                     c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
                 }
+            } else if (BRICK9) {
+                // cell coords c = i + 1 in [0, n]; brick c >> 3, local c & 7; the taps sit at local
+                // (l, l+1) per axis of the 9^3 brick: offsets {0,1} + {0,9} + {0,81} from one base
+                const int cx = med3_i32(ix, -1, mx) + 1, cy = med3_i32(iy, -1, my) + 1, cz = med3_i32(iz, -1, mz) + 1;
+                const uint32_t brick = (uint32_t)(((cz >> 3) * (int)V.nby + (cy >> 3)) * (int)V.nbx + (cx >> 3));
+                const uint32_t local = (uint32_t)((cz & 7) * 81 + (cy & 7) * 9 + (cx & 7));
+                typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+                typedef uint32_t u32_unaligned __attribute__((aligned(2)));
+                float tp[8];
+                if (VOL == VOL_B9U8) {
+                    const uint8_t *b = reinterpret_cast<const uint8_t *>(V.data) + ((uint64_t)brick * 729u + local);
+                    const uint32_t p00 = *reinterpret_cast<const u16_unaligned *>(b), p10 = *reinterpret_cast<const u16_unaligned *>(b + 9);
+                    const uint32_t p01 = *reinterpret_cast<const u16_unaligned *>(b + 81), p11 = *reinterpret_cast<const u16_unaligned *>(b + 90);
+                    tp[0] = (float)(p00 & 0xffu); tp[1] = (float)(p00 >> 8); tp[2] = (float)(p10 & 0xffu); tp[3] = (float)(p10 >> 8);
+                    tp[4] = (float)(p01 & 0xffu); tp[5] = (float)(p01 >> 8); tp[6] = (float)(p11 & 0xffu); tp[7] = (float)(p11 >> 8);
+                } else {
+                    const uint16_t *b = reinterpret_cast<const uint16_t *>(V.data) + ((uint64_t)brick * 729u + local);
+                    const uint32_t p00 = *reinterpret_cast<const u32_unaligned *>(b), p10 = *reinterpret_cast<const u32_unaligned *>(b + 9);
+                    const uint32_t p01 = *reinterpret_cast<const u32_unaligned *>(b + 81), p11 = *reinterpret_cast<const u32_unaligned *>(b + 90);
+                    tp[0] = h2f(p00 & 0xffffu); tp[1] = h2f(p00 >> 16); tp[2] = h2f(p10 & 0xffffu); tp[3] = h2f(p10 >> 16);
+                    tp[4] = h2f(p01 & 0xffffu); tp[5] = h2f(p01 >> 16); tp[6] = h2f(p11 & 0xffffu); tp[7] = h2f(p11 >> 16);
+                }
+                c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+                c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
             } else {
                 int x0 = clampi(ix, 0, mx), x1 = clampi(ix + (ix < 0x7fffffff), 0, mx);
                 int y0 = clampi(iy, 0, my), y1 = clampi(iy + (iy < 0x7fffffff), 0, my);
@@ -382,7 +411,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             }
             float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
             float r = fmaf(fz, c1 - c0, c0);
-            if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8) r = r * (1.0f / 255.0f);
+            if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) r = r * (1.0f / 255.0f);
             const float a = transfer_alpha(r);
             // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
             constexpr double kk = 6.28318 / 6.283185307179586476925;
@@ -518,7 +547,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
 template <int VOL>
 __global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict__ src, void *__restrict__ dst,
                                                           uint8_t *__restrict__ occ, uint32_t nx, uint32_t ny,
-                                                          uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_cells) {
+                                                          uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_cells,
+                                                          unsigned long long *__restrict__ n_empty) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_cells) return;
     uint64_t brick = id >> 6;
@@ -544,6 +574,10 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict_
 #pragma unroll
     for (int b = 0; b < 8; b++) nonempty |= (VOL == VOL_PF16) ? !(h2f(t[b]) <= 0.1f) : (t[b] > 25u);
     occ[id] = nonempty ? 0 : 255;
+    {   // census of exactly-transparent cells (one atomic per wave): decides whether skipping can pay
+        const unsigned long long m = __ballot(!nonempty);
+        if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_empty, (unsigned long long)__popcll(m));
+    }
     if (VOL == VOL_P8) {
         uint32_t lo = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
         uint32_t hi = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
@@ -558,6 +592,27 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict_
         reinterpret_cast<uint4 *>(dst)[id] = c.u;
     } else {
         reinterpret_cast<uint4 *>(dst)[id] = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+    }
+}
+
+// Dense voxels -> 9^3 bricks: one thread per stored voxel, brick b holds voxels [8b-1, 8b+7] per axis
+// (clamped to the volume: clamp-to-edge is baked in).
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_bricks9_kernel(const void *__restrict__ src, void *__restrict__ dst, uint32_t nx,
+                                                           uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_elems) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_elems; id += stride) {  // may exceed 2^32
+        uint64_t brick = id / 729u;
+        uint32_t l = (uint32_t)(id - brick * 729u);
+        uint32_t lz = l / 81u, ly = (l - lz * 81u) / 9u, lx = l - lz * 81u - ly * 9u;
+        uint32_t bx = (uint32_t)(brick % nbx);
+        uint64_t rest = brick / nbx;
+        uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        int x = clampi((int)(bx * 8 + lx) - 1, 0, (int)nx - 1), y = clampi((int)(by * 8 + ly) - 1, 0, (int)ny - 1);
+        int z = clampi((int)(bz * 8 + lz) - 1, 0, (int)nz - 1);
+        size_t idx = (size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)z);
+        if (F16) reinterpret_cast<uint16_t *>(dst)[id] = reinterpret_cast<const uint16_t *>(src)[idx];
+        else reinterpret_cast<uint8_t *>(dst)[id] = reinterpret_cast<const uint8_t *>(src)[idx];
     }
 }
 
@@ -660,18 +715,18 @@ __device__ __forceinline__ uint32_t standin_voxel(uint32_t x, uint32_t y, uint32
 template <int KIND>
 __global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
                                                        uint32_t seed, uint32_t lo, uint32_t span) {
-    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t n = (uint64_t)nx * ny * nz;
-    if (id >= n) return;
-    uint32_t x = (uint32_t)(id % nx);
-    uint64_t rest = id / nx;
-    uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
-    if (KIND == 2) {
-        reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)standin_voxel(x, y, z, nx, ny, nz, seed);
-    } else {
-        uint32_t h = hash3(x, y, z, seed) >> 8;
-        if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(0x2D1Fu + h % 656u);
-        else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(lo + h % span);
+    const uint64_t n = (uint64_t)nx * ny * nz, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += stride) {  // grid-stride: n may exceed 2^32
+        uint32_t x = (uint32_t)(id % nx);
+        uint64_t rest = id / nx;
+        uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
+        if (KIND == 2) {
+            reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)standin_voxel(x, y, z, nx, ny, nz, seed);
+        } else {
+            uint32_t h = hash3(x, y, z, seed) >> 8;
+            if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(0x2D1Fu + h % 656u);
+            else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(lo + h % span);
+        }
     }
 }
 
