@@ -167,8 +167,10 @@ int vk_step_counts_reset(vk_ctx *ctx);
  * out[0] wave-level march-loop iterations, out[1] wave-level skipped-step iterations,
  * out[2] wave-level sample executions, out[3] per-lane march-loop iterations (lookups). */
 int vk_simt_census(vk_ctx *ctx, uint64_t out[4]);
-/* Debug: per-8x8-block {first start, last end} s_memrealtime stamps (100 MHz) of the next
- * VK_RENDER_COUNT NAIVE launch.  enable != 0 arms it; out != NULL copies n_blocks pairs back. */
+/* Debug: per-8x8-block {first start, last end, HW_ID | XCC_ID << 32, work} of the next VK_RENDER_COUNT NAIVE
+ * launch (s_memrealtime stamps).  enable != 0 arms it; out != NULL copies n_blocks quadruples back. */
+/* Debug: override the tile order table (experiments on launch order). */
+int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n);
 int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks);
 /* Per-pixel executed loop iterations of the last VK_RENDER_COUNT launch ([height][width] u32). */
 int vk_readback_steps(vk_ctx *ctx, uint32_t *dst);

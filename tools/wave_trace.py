@@ -14,10 +14,12 @@ pipe.record(ctx); ctx.sync()
 nb = 30 * 17 * 64
 N.check(ctx.handle, N.lib().vk_debug_wave_trace(ctx.handle, 1, None, 0))
 pipe.record(ctx); ctx.sync()
-buf = np.zeros(nb * 2, np.uint64)
+buf = np.zeros(nb * 4, np.uint64)
 N.check(ctx.handle, N.lib().vk_debug_wave_trace(ctx.handle, 0, buf.ctypes.data_as(C.POINTER(C.c_uint64)), nb))
-st, en = buf[0::2].astype(np.int64), buf[1::2].astype(np.int64)
+st, en, where, work = buf[0::4].astype(np.int64), buf[1::4].astype(np.int64), buf[2::4], buf[3::4]
 ok = en > 0
+where = where[ok]
+work = work[ok]
 t0 = st[ok].min()
 st, en = (st[ok] - t0) / 100.0, (en[ok] - t0) / 100.0   # us
 dur = en - st
@@ -30,4 +32,28 @@ for a, b in zip(edges[:-1], edges[1:]):
     print(f"t={mid:7.1f} us  in flight {int(((st <= mid) & (en > mid)).sum()):6d}")
 long_ = np.argsort(-dur)[:10]
 print("longest blocks: start, end:", [(round(st[i], 1), round(en[i], 1)) for i in long_])
+hw = (where & np.uint64(0xffffffff)).astype(np.int64); xcc = (where >> np.uint64(32)).astype(np.int64) & 0xf
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+uk, inv = np.unique(key, return_inverse=True)
+load = np.bincount(inv, weights=dur)
+heavy = np.bincount(inv, weights=(dur > np.percentile(dur, 90)).astype(float))
+full = buf[2::4]
+print("placement of the first logical blocks (lb: xcc se sh cu simd wave):")
+for lb in list(range(0, 40)) + list(range(64, 72)) + list(range(512, 520)):
+    w_ = int(full[lb]); h_ = w_ & 0xffffffff
+    print(lb, (w_ >> 32) & 0xf, (h_ >> 13) & 7, (h_ >> 12) & 1, (h_ >> 8) & 15, (h_ >> 4) & 3, h_ & 15, end=" | ")
+print()
+print("distinct SIMDs seen", len(uk), "xcc values", np.unique(xcc), "se", np.unique(se), "cu", np.unique(cu))
+print("per-SIMD summed wave time: mean %.0f  p50 %.0f  p90 %.0f  max %.0f   (frame span %.0f)" % (load.mean(), np.percentile(load, 50), np.percentile(load, 90), load.max(), en.max()))
+print("heavy (top-10%%) waves per SIMD: mean %.2f max %d  hist %s" % (heavy.mean(), heavy.max(), np.bincount(heavy.astype(int)).tolist()))
+wo = (work & np.uint64(0xfffff)).astype(np.float64); wi = ((work >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.float64); ws = (work >> np.uint64(40)).astype(np.float64)
+est = wo * 35 + wi * 7 + ws * 35          # issue-slot estimate per wave
+wl = np.bincount(inv, weights=est)
+print("per-SIMD estimated work (issue slots): mean %.0f p50 %.0f p90 %.0f max %.0f  -> max/mean %.2f" % (wl.mean(), np.percentile(wl, 50), np.percentile(wl, 90), wl.max(), wl.max() / wl.mean()))
+cu_key = key // 4; ucu, icu = np.unique(cu_key, return_inverse=True); wcu = np.bincount(icu, weights=est)
+print("per-CU estimated work: mean %.0f max %.0f min %.0f -> max/mean %.2f" % (wcu.mean(), wcu.max(), wcu.min(), wcu.max() / wcu.mean()))
+xk = xcc; wx = np.bincount(xk, weights=est); print("per-XCD estimated work:", (wx / wx.mean()).round(3).tolist())
+percu = np.bincount((key // 4).astype(np.int64) - (key // 4).min(), weights=dur); percu = percu[percu > 0]
+print("per-CU summed wave time: mean %.0f max %.0f min %.0f" % (percu.mean(), percu.max(), percu.min()))
 ctx.close()

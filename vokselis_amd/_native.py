@@ -51,6 +51,7 @@ SYMBOLS = {
     "vk_step_counts": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vk_step_counts_reset": (C.c_int, [_vp]),
     "vk_simt_census": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "vk_debug_set_tile_order": (C.c_int, [_vp, C.POINTER(_u32), _u32]),
     "vk_debug_wave_trace": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _sz]),
     "vk_readback_steps": (C.c_int, [_vp, _vp]),
     "vk_timer_begin": (C.c_int, [_vp]),

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -684,12 +685,12 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);
             ctx->trace = nullptr; ctx->trace_blocks = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 2 * sizeof(unsigned long long)));
+            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 4 * sizeof(unsigned long long)));
             ctx->trace_blocks = n_blocks;
         }
         // start = +inf (atomicMin), end = 0 (atomicMax): fill {0xff.., 0} pairs
-        std::vector<unsigned long long> init(n_blocks * 2);
-        for (uint64_t i = 0; i < n_blocks; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+        std::vector<unsigned long long> init(n_blocks * 4, 0ull);
+        for (uint64_t i = 0; i < n_blocks; i++) init[4 * i] = ~0ull;
         HIP_TRY(ctx, hipMemcpy(ctx->trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         L.trace = ctx->trace;
     }
@@ -766,6 +767,18 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
     if (orc) return orc;
     if (n_active_tiles) *n_active_tiles = ctx->order_active;
     if (n_active_slots) *n_active_slots = (ctx->order_active + nranks - 1) / nranks;
+    return VK_OK;
+}
+
+int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n) {
+    // experiment hook: replace the current (already computed) order table; stays until the key changes
+    if (!ctx || !order) return VK_ERR_INVALID;
+    if (n != ctx->order.size() || !ctx->d_order) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: no order of that size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < n; q++) { ctx->order[q] = order[q]; ctx->order_pos[order[q]] = q; }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     return VK_OK;
 }
 
@@ -889,7 +902,7 @@ int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks)
     if (!ctx->trace || n_blocks > ctx->trace_blocks) return fail(ctx, VK_ERR_INVALID, "vk_debug_wave_trace: no trace of that size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->trace, n_blocks * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->trace, n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VK_OK;
 }
 

@@ -72,7 +72,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
-    unsigned long long *trace;     // optional per-block {start, end} s_memrealtime stamps (COUNT builds)
+    unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------
@@ -81,6 +81,9 @@ struct LaunchDesc {
 // logical blocks = the 64 waves of one 64x64 pixel tile: neighbouring rays share an L2, while
 // successive tiles still spread over all XCDs (the frame is ~70 % empty, so contiguous bands
 // per XCD would not balance).  Speed only -- nothing depends on the placement.
+// (A persistent variant -- one wave per hardware slot pulling blocks from per-XCD atomic queues --
+// balanced the per-SIMD work better (max/mean 1.62 -> 1.45) but lost 0.235 -> 0.35 ms to the
+// dequeue round trips of ~32 k mostly trivial blocks: tools/experiments/persistent_workqueue.patch.)
 __device__ __forceinline__ uint32_t logical_block(uint32_t b) {
     uint32_t group = b >> 9, r = b & 511u;
     return (group << 9) + ((r & 7u) << 6) + (r >> 3);
@@ -445,8 +448,13 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         }
         if (L.trace) {  // stamps leave only through this debug buffer
             unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-            atomicMin(&L.trace[2 * (size_t)lb], t_start);
-            atomicMax(&L.trace[2 * (size_t)lb + 1], t_end);
+            atomicMin(&L.trace[4 * (size_t)lb], t_start);
+            atomicMax(&L.trace[4 * (size_t)lb + 1], t_end);
+            // where the wave ran: HW_ID (wave/simd/cu/sh/se fields) and XCC_ID
+            L.trace[4 * (size_t)lb + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            // wave-level work: march-loop trips | skip-walk trips << 20 | sample executions << 40
+            atomicAdd(&L.trace[4 * (size_t)lb + 3], (unsigned long long)w_outer | ((unsigned long long)w_inner << 20) | ((unsigned long long)w_sample << 40));
         }
     }
 }
