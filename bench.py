@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
-    ap.add_argument("--layout", default="pairs", choices=["pairs", "packed"], help="cell format of the u8 volume")
+    ap.add_argument("--layout", default="pairs", choices=["pairs", "packed", "bricked"], help="cell format of the u8 volume")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather path even at N = 1 (self-test)")
@@ -149,7 +149,7 @@ def main():
     import vokselis_amd as V
     from vokselis_amd.dist import TileParallelRenderer
 
-    layout = V.LAYOUT_PACKED_PAIRS if args.layout == "pairs" else V.LAYOUT_PACKED
+    layout = {"pairs": V.LAYOUT_PACKED_PAIRS, "packed": V.LAYOUT_PACKED, "bricked": V.LAYOUT_BRICKED}[args.layout]
     flags = V.RENDER_NO_SKIP if args.no_skip else 0
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -221,7 +221,7 @@ def main():
                 "config": {
                     "workload": "C2: bonsai stand-in 256^3 uint8 (device-generated, seed 0x5EED0001), 1920x1080, "
                                 "bonsai camera (1,.5,1,(.5,.5,.5)), NAIVE_TRILINEAR, dt_scale 0.5 (<=513 steps/ray), rgba16f out",
-                    "layout": "4^3-bricked cells, " + ("4 (tap,delta) f16 pairs / 16 B" if args.layout == "pairs" else "8 u8 taps / 8 B"),
+                    "layout": {"pairs": "4^3-bricked cells, 4 (tap,delta) f16 pairs / 16 B", "packed": "4^3-bricked cells, 8 u8 taps / 8 B", "bricked": "dense 9^3 bricks, 8 scalar taps"}[args.layout],
                     "skip": not args.no_skip,
                     "partition": "single launch" if world == 1 else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,

@@ -300,7 +300,10 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         }
 
         float t = t0;
-        while (t < t1) {  // :101
+        // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
+        // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
+        // changes nothing observable.
+        while (t < t1 && A < 0.95f) {
             if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
             const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
             int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
@@ -427,7 +430,6 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             const float w = (1.0f - A) * a;  // :112-114
             Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
             A = A + w;
-            if (A >= 0.95f) break;  // :115-117
             px = px + sx; py = py + sy; pz = pz + sz;  // :118
             t = t + dt;
         }
