@@ -59,7 +59,8 @@ enum vk_render_flags {
     VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
     VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
     VK_RENDER_SAFE = 4,     /* force the clamped / 64-bit-offset kernel variant */
-    VK_RENDER_FORCE_SKIP = 8 /* skip even when < 10 % of the cells are transparent (default: auto) */
+    VK_RENDER_FORCE_SKIP = 8, /* skip even when < 10 % of the cells are transparent (default: auto) */
+    VK_RENDER_DEBUG_TRIPS = 16 /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */

@@ -681,6 +681,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.steps = count ? ctx->steps : nullptr;
     L.counters = count ? ctx->counters : nullptr;
     L.trace = nullptr;
+    L.debug_flags = (flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u;
     if (count && ctx->want_trace) {
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);

@@ -72,6 +72,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
+    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds)
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
 };
 
@@ -234,11 +235,189 @@ __device__ __forceinline__ bool wave_leader() {
     return (int)(threadIdx.x & 63u) == __ffsll((unsigned long long)__ballot(1)) - 1;
 }
 
-template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
-__global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
+// ---- the march, resumable ---------------------------------------------------------------------
+// Everything a ray needs to continue: the accumulators of the reference loop (t, p, alpha, colour
+// sums), its per-ray constants and where its pixel goes.  64 bytes.
+struct RayState {
+    float t, t1, dt, px, py, pz, sx, sy, sz, A, Gr, Gg, Gb;
+    uint32_t out;        // pixel index into the launch's output
+    uint32_t pad[2];
+};
+static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
+
+struct Census {  // SIMT execution census + step counters (COUNT builds only)
+    uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0;
+};
+
+// Runs at most `budget` trips of the reference loop (raycast_naive.wgsl:101-119) on the state and
+// returns whether the ray is still alive.  State in, state out: a ray marched in several pieces
+// goes through exactly the same f32 operations as one marched in one go.
+template <int VOL, bool SKIP, bool SAFE, bool COUNT>
+__device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
     constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
-    static_assert(PACKED || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
+    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+    uint32_t &n_iter = cs.n_iter, &n_samp = cs.n_samp, &w_outer = cs.w_outer, &w_inner = cs.w_inner, &w_sample = cs.w_sample, &n_look = cs.n_look;
+    const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
+
+    // per-ray constants of the skip bound (see below)
+    // Skip bound per axis: room_i / |du_i| with room_i = d - f_i (moving up) or f_i + d - 1 (moving
+    // down), minus a 0.02-cell margin that covers the rounding of the accumulated position
+    // (<= 1e-3 cells); folded into two fmas: r_i = f_i * ska_i + (d * idu_i + skb_i).
+    float idux = 0.f, iduy = 0.f, iduz = 0.f, skax = 0.f, skay = 0.f, skaz = 0.f, skbx = 0.f, skby = 0.f, skbz = 0.f;
+    float inv_dt = 0.f;
+    if (SKIP) {
+        inv_dt = __builtin_amdgcn_rcpf(dt);  // only bounds a skip length (2 steps of slack below)
+        idux = __builtin_amdgcn_rcpf(fabsf(sx) * fnx); iduy = __builtin_amdgcn_rcpf(fabsf(sy) * fny); iduz = __builtin_amdgcn_rcpf(fabsf(sz) * fnz);
+        skax = sx >= 0.0f ? -idux : idux; skay = sy >= 0.0f ? -iduy : iduy; skaz = sz >= 0.0f ? -iduz : iduz;
+        skbx = (sx >= 0.0f ? -0.02f : -1.02f) * idux; skby = (sy >= 0.0f ? -0.02f : -1.02f) * iduy;
+        skbz = (sz >= 0.0f ? -0.02f : -1.02f) * iduz;
+    }
+
+    // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
+    // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
+    // changes nothing observable.
+    uint32_t trip = 0;  // wave-uniform: the active lanes of a wave entered the loop together
+    while (t < t1 && A < 0.95f && trip < budget) {
+        ++trip;
+        if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
+        const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+        float c00, c10, c01, c11;  // x-lerped corners
+        if (PACKED) {
+            if (SAFE) { ix = med3_i32(ix, -1, mx); iy = med3_i32(iy, -1, my); iz = med3_i32(iz, -1, mz); }
+            const int bx = ix >> 2, by = iy >> 2, bz = iz >> 2;
+            const char *cptr;
+            uint32_t d = 0;
+            if (SAFE) {
+                int64_t off = (int64_t)bz * (int64_t)V.kz + (int64_t)(by * (int)V.ky + bx * (int)V.kx) +
+                              (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
+                off = off < 0 ? 0 : (off > (int64_t)V.max_off ? (int64_t)V.max_off : off);
+                cptr = reinterpret_cast<const char *>(V.data) + off;
+                if (SKIP) d = V.dist[off >> V.sh_x];
+            } else {
+                // cell index, affine in (i, i >> 2)
+                const uint32_t acc = (uint32_t)(bz * V.ciz + by * V.ciy + bx * 60 + (iz << 4) + (iy << 2) + ix + V.ci0);
+                const uint32_t idx = min(acc, V.max_idx);  // memory-safety net; never binds for valid rays
+                cptr = reinterpret_cast<const char *>(V.data) + (uint32_t)(idx << V.sh_x);  // < 2 GiB: SGPR base + 32-bit offset
+                if (SKIP) d = V.dist[idx];
+            }
+            if (SKIP && d != 0) {
+                // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
+                // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
+                // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margin.
+                const float fd = (float)d;
+                const float rx = fmaf(fx, skax, fmaf(fd, idux, skbx));
+                const float ry = fmaf(fy, skay, fmaf(fd, iduy, skby));
+                const float rz = fmaf(fz, skaz, fmaf(fd, iduz, skbz));
+                // ... and never past the ray's end: iterations j <= (t1 - t)/dt - 2 certainly see
+                // t < t1, so the walk needs no float compare; the last couple of iterations of a
+                // ray fall back to single steps, where the loop's own `t < t1` test decides.
+                const float rend = fmaf(t1 - t, inv_dt, -2.0f);
+                // float -> u32 conversion saturates negatives and NaN to 0; +1: the current sample is
+                // always skippable (its cell is empty)
+                uint32_t k = cvt_u32_sat(fminf(fminf(rx, rend), fminf(ry, rz))) + 1u;
+                do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
+                    px = px + sx; py = py + sy; pz = pz + sz;
+                    t = t + dt;
+                    if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
+                } while (--k > 0);
+                continue;
+            }
+            if (VOL == VOL_P8) {
+                uint2 c = *reinterpret_cast<const uint2 *>(cptr);
+                float t0_ = (float)(c.x & 0xffu), t1_ = (float)((c.x >> 8) & 0xffu);
+                float t2_ = (float)((c.x >> 16) & 0xffu), t3_ = (float)(c.x >> 24);
+                float t4_ = (float)(c.y & 0xffu), t5_ = (float)((c.y >> 8) & 0xffu);
+                float t6_ = (float)((c.y >> 16) & 0xffu), t7_ = (float)(c.y >> 24);
+                c00 = fmaf(fx, t1_ - t0_, t0_); c10 = fmaf(fx, t3_ - t2_, t2_);
+                c01 = fmaf(fx, t5_ - t4_, t4_); c11 = fmaf(fx, t7_ - t6_, t6_);
+            } else if (VOL == VOL_P16) {
+                union { uint4 u; half2_t h[4]; } c;
+                c.u = *reinterpret_cast<const uint4 *>(cptr);
+                // (tap, delta) pairs: delta = t1 - t0 is exact in f16 for u8 data -> v_fma_mix_f32
+                c00 = fmaf(fx, (float)c.h[0].y, (float)c.h[0].x); c10 = fmaf(fx, (float)c.h[1].y, (float)c.h[1].x);
+                c01 = fmaf(fx, (float)c.h[2].y, (float)c.h[2].x); c11 = fmaf(fx, (float)c.h[3].y, (float)c.h[3].x);
+            } else {
+                union { uint4 u; half2_t h[4]; } c;
+                c.u = *reinterpret_cast<const uint4 *>(cptr);
+                float a0 = (float)c.h[0].x, a1 = (float)c.h[0].y, a2 = (float)c.h[1].x, a3 = (float)c.h[1].y;
+                float a4 = (float)c.h[2].x, a5 = (float)c.h[2].y, a6 = (float)c.h[3].x, a7 = (float)c.h[3].y;
+                c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
+                c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
+            }
+        } else if (BRICK9) {
+            // cell coords c = i + 1 in [0, n]; brick c >> 3, local c & 7; the taps sit at local
+            // (l, l+1) per axis of the 9^3 brick: offsets {0,1} + {0,9} + {0,81} from one base
+            const int cx = med3_i32(ix, -1, mx) + 1, cy = med3_i32(iy, -1, my) + 1, cz = med3_i32(iz, -1, mz) + 1;
+            const uint32_t brick = (uint32_t)(((cz >> 3) * (int)V.nby + (cy >> 3)) * (int)V.nbx + (cx >> 3));
+            const uint32_t local = (uint32_t)((cz & 7) * 81 + (cy & 7) * 9 + (cx & 7));
+            typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+            typedef uint32_t u32_unaligned __attribute__((aligned(2)));
+            float tp[8];
+            if (VOL == VOL_B9U8) {
+                const uint8_t *b = reinterpret_cast<const uint8_t *>(V.data) + ((uint64_t)brick * 729u + local);
+                const uint32_t p00 = *reinterpret_cast<const u16_unaligned *>(b), p10 = *reinterpret_cast<const u16_unaligned *>(b + 9);
+                const uint32_t p01 = *reinterpret_cast<const u16_unaligned *>(b + 81), p11 = *reinterpret_cast<const u16_unaligned *>(b + 90);
+                tp[0] = (float)(p00 & 0xffu); tp[1] = (float)(p00 >> 8); tp[2] = (float)(p10 & 0xffu); tp[3] = (float)(p10 >> 8);
+                tp[4] = (float)(p01 & 0xffu); tp[5] = (float)(p01 >> 8); tp[6] = (float)(p11 & 0xffu); tp[7] = (float)(p11 >> 8);
+            } else {
+                const uint16_t *b = reinterpret_cast<const uint16_t *>(V.data) + ((uint64_t)brick * 729u + local);
+                const uint32_t p00 = *reinterpret_cast<const u32_unaligned *>(b), p10 = *reinterpret_cast<const u32_unaligned *>(b + 9);
+                const uint32_t p01 = *reinterpret_cast<const u32_unaligned *>(b + 81), p11 = *reinterpret_cast<const u32_unaligned *>(b + 90);
+                tp[0] = h2f(p00 & 0xffffu); tp[1] = h2f(p00 >> 16); tp[2] = h2f(p10 & 0xffffu); tp[3] = h2f(p10 >> 16);
+                tp[4] = h2f(p01 & 0xffffu); tp[5] = h2f(p01 >> 16); tp[6] = h2f(p11 & 0xffffu); tp[7] = h2f(p11 >> 16);
+            }
+            c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+            c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
+        } else {
+            int x0 = clampi(ix, 0, mx), x1 = clampi(ix + (ix < 0x7fffffff), 0, mx);
+            int y0 = clampi(iy, 0, my), y1 = clampi(iy + (iy < 0x7fffffff), 0, my);
+            int z0 = clampi(iz, 0, mz), z1 = clampi(iz + (iz < 0x7fffffff), 0, mz);
+            size_t sy_ = V.nx, sz_ = (size_t)V.nx * V.ny;
+            size_t r00 = y0 * sy_ + z0 * sz_, r10 = y1 * sy_ + z0 * sz_;
+            size_t r01 = y0 * sy_ + z1 * sz_, r11 = y1 * sy_ + z1 * sz_;
+            float tp[8];
+            if (VOL == VOL_LINEAR_U8) {
+                const uint8_t *v = reinterpret_cast<const uint8_t *>(V.data);
+                tp[0] = (float)v[r00 + x0]; tp[1] = (float)v[r00 + x1]; tp[2] = (float)v[r10 + x0]; tp[3] = (float)v[r10 + x1];
+                tp[4] = (float)v[r01 + x0]; tp[5] = (float)v[r01 + x1]; tp[6] = (float)v[r11 + x0]; tp[7] = (float)v[r11 + x1];
+            } else {
+                const uint16_t *v = reinterpret_cast<const uint16_t *>(V.data);
+                tp[0] = h2f(v[r00 + x0]); tp[1] = h2f(v[r00 + x1]); tp[2] = h2f(v[r10 + x0]); tp[3] = h2f(v[r10 + x1]);
+                tp[4] = h2f(v[r01 + x0]); tp[5] = h2f(v[r01 + x1]); tp[6] = h2f(v[r11 + x0]); tp[7] = h2f(v[r11 + x1]);
+            }
+            c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+            c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
+        }
+        float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
+        float r = fmaf(fz, c1 - c0, c0);
+        if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) r = r * (1.0f / 255.0f);
+        const float a = transfer_alpha(r);
+        // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
+        constexpr double kk = 6.28318 / 6.283185307179586476925;
+        constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+        constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+        const float cr = __builtin_amdgcn_cosf(a * pc0);
+        const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+        const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+        if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
+        const float w = (1.0f - A) * a;  // :112-114
+        Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
+        A = A + w;
+        px = px + sx; py = py + sy; pz = pz + sz;  // :118
+        t = t + dt;
+    }
+    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    return t < t1 && A < 0.95f;
+}
+
+template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
+    static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
@@ -269,8 +448,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
 
     float t0, t1;
     intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
-    uint32_t n_iter = 0, n_samp = 0;
-    uint32_t w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0;  // SIMT execution census (COUNT builds)
+    Census cs;
     // colour is accumulated as G = sum w*cos(phase); C = 0.5*A + 0.5*G at the end (sum w == A)
     float Gr = 0.0f, Gg = 0.0f, Gb = 0.0f, A = 0.0f;
     float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
@@ -283,170 +461,27 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         const float dt = L.dt_scale * fminf(dtx, fminf(dty, dtz));  // :97-99
         float px = eye[0] + t0 * dir[0], py = eye[1] + t0 * dir[1], pz = eye[2] + t0 * dir[2];  // :100
         const float sx = dir[0] * dt, sy = dir[1] * dt, sz = dir[2] * dt;  // :118
-        const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
-
-        // per-ray constants of the skip bound (see below)
-        // Skip bound per axis: room_i / |du_i| with room_i = d - f_i (moving up) or f_i + d - 1 (moving
-        // down), minus a 0.02-cell margin that covers the rounding of the accumulated position
-        // (<= 1e-3 cells); folded into two fmas: r_i = f_i * ska_i + (d * idu_i + skb_i).
-        float idux = 0.f, iduy = 0.f, iduz = 0.f, skax = 0.f, skay = 0.f, skaz = 0.f, skbx = 0.f, skby = 0.f, skbz = 0.f;
-        float inv_dt = 0.f;
-        if (SKIP) {
-            inv_dt = __builtin_amdgcn_rcpf(dt);  // only bounds a skip length (2 steps of slack below)
-            idux = 1.0f / (fabsf(sx) * fnx); iduy = 1.0f / (fabsf(sy) * fny); iduz = 1.0f / (fabsf(sz) * fnz);
-            skax = sx >= 0.0f ? -idux : idux; skay = sy >= 0.0f ? -iduy : iduy; skaz = sz >= 0.0f ? -iduz : iduz;
-            skbx = (sx >= 0.0f ? -0.02f : -1.02f) * idux; skby = (sy >= 0.0f ? -0.02f : -1.02f) * iduy;
-            skbz = (sz >= 0.0f ? -0.02f : -1.02f) * iduz;
-        }
-
-        float t = t0;
-        // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
-        // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
-        // changes nothing observable.
-        while (t < t1 && A < 0.95f) {
-            if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
-            const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
-            int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
-            const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
-            float c00, c10, c01, c11;  // x-lerped corners
-            if (PACKED) {
-                if (SAFE) { ix = med3_i32(ix, -1, mx); iy = med3_i32(iy, -1, my); iz = med3_i32(iz, -1, mz); }
-                const int bx = ix >> 2, by = iy >> 2, bz = iz >> 2;
-                const char *cptr;
-                uint32_t d = 0;
-                if (SAFE) {
-                    int64_t off = (int64_t)bz * (int64_t)V.kz + (int64_t)(by * (int)V.ky + bx * (int)V.kx) +
-                                  (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
-                    off = off < 0 ? 0 : (off > (int64_t)V.max_off ? (int64_t)V.max_off : off);
-                    cptr = reinterpret_cast<const char *>(V.data) + off;
-                    if (SKIP) d = V.dist[off >> V.sh_x];
-                } else {
-                    // cell index, affine in (i, i >> 2)
-                    const uint32_t acc = (uint32_t)(bz * V.ciz + by * V.ciy + bx * 60 + (iz << 4) + (iy << 2) + ix + V.ci0);
-                    const uint32_t idx = min(acc, V.max_idx);  // memory-safety net; never binds for valid rays
-                    cptr = reinterpret_cast<const char *>(V.data) + (uint32_t)(idx << V.sh_x);  // < 2 GiB: SGPR base + 32-bit offset
-                    if (SKIP) d = V.dist[idx];
-                }
-                if (SKIP && d != 0) {
-                    // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
-                    // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
-                    // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margin.
-                    const float fd = (float)d;
-                    const float rx = fmaf(fx, skax, fmaf(fd, idux, skbx));
-                    const float ry = fmaf(fy, skay, fmaf(fd, iduy, skby));
-                    const float rz = fmaf(fz, skaz, fmaf(fd, iduz, skbz));
-                    // ... and never past the ray's end: iterations j <= (t1 - t)/dt - 2 certainly see
-                    // t < t1, so the walk needs no float compare; the last couple of iterations of a
-                    // ray fall back to single steps, where the loop's own `t < t1` test decides.
-                    const float rend = fmaf(t1 - t, inv_dt, -2.0f);
-                    // float -> u32 conversion saturates negatives and NaN to 0; +1: the current sample is
-                    // always skippable (its cell is empty)
-                    uint32_t k = cvt_u32_sat(fminf(fminf(rx, rend), fminf(ry, rz))) + 1u;
-                    do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
-                        px = px + sx; py = py + sy; pz = pz + sz;
-                        t = t + dt;
-                        if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
-                    } while (--k > 0);
-                    continue;
-                }
-                if (VOL == VOL_P8) {
-                    uint2 c = *reinterpret_cast<const uint2 *>(cptr);
-                    float t0_ = (float)(c.x & 0xffu), t1_ = (float)((c.x >> 8) & 0xffu);
-                    float t2_ = (float)((c.x >> 16) & 0xffu), t3_ = (float)(c.x >> 24);
-                    float t4_ = (float)(c.y & 0xffu), t5_ = (float)((c.y >> 8) & 0xffu);
-                    float t6_ = (float)((c.y >> 16) & 0xffu), t7_ = (float)(c.y >> 24);
-                    c00 = fmaf(fx, t1_ - t0_, t0_); c10 = fmaf(fx, t3_ - t2_, t2_);
-                    c01 = fmaf(fx, t5_ - t4_, t4_); c11 = fmaf(fx, t7_ - t6_, t6_);
-                } else if (VOL == VOL_P16) {
-                    union { uint4 u; half2_t h[4]; } c;
-                    c.u = *reinterpret_cast<const uint4 *>(cptr);
-                    // (tap, delta) pairs: delta = t1 - t0 is exact in f16 for u8 data -> v_fma_mix_f32
-                    c00 = fmaf(fx, (float)c.h[0].y, (float)c.h[0].x); c10 = fmaf(fx, (float)c.h[1].y, (float)c.h[1].x);
-                    c01 = fmaf(fx, (float)c.h[2].y, (float)c.h[2].x); c11 = fmaf(fx, (float)c.h[3].y, (float)c.h[3].x);
-                } else {
-                    union { uint4 u; half2_t h[4]; } c;
-                    c.u = *reinterpret_cast<const uint4 *>(cptr);
-                    float a0 = (float)c.h[0].x, a1 = (float)c.h[0].y, a2 = (float)c.h[1].x, a3 = (float)c.h[1].y;
-                    float a4 = (float)c.h[2].x, a5 = (float)c.h[2].y, a6 = (float)c.h[3].x, a7 = (float)c.h[3].y;
-                    c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
-                    c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
-                }
-            } else if (BRICK9) {
-                // cell coords c = i + 1 in [0, n]; brick c >> 3, local c & 7; the taps sit at local
-                // (l, l+1) per axis of the 9^3 brick: offsets {0,1} + {0,9} + {0,81} from one base
-                const int cx = med3_i32(ix, -1, mx) + 1, cy = med3_i32(iy, -1, my) + 1, cz = med3_i32(iz, -1, mz) + 1;
-                const uint32_t brick = (uint32_t)(((cz >> 3) * (int)V.nby + (cy >> 3)) * (int)V.nbx + (cx >> 3));
-                const uint32_t local = (uint32_t)((cz & 7) * 81 + (cy & 7) * 9 + (cx & 7));
-                typedef uint16_t u16_unaligned __attribute__((aligned(1)));
-                typedef uint32_t u32_unaligned __attribute__((aligned(2)));
-                float tp[8];
-                if (VOL == VOL_B9U8) {
-                    const uint8_t *b = reinterpret_cast<const uint8_t *>(V.data) + ((uint64_t)brick * 729u + local);
-                    const uint32_t p00 = *reinterpret_cast<const u16_unaligned *>(b), p10 = *reinterpret_cast<const u16_unaligned *>(b + 9);
-                    const uint32_t p01 = *reinterpret_cast<const u16_unaligned *>(b + 81), p11 = *reinterpret_cast<const u16_unaligned *>(b + 90);
-                    tp[0] = (float)(p00 & 0xffu); tp[1] = (float)(p00 >> 8); tp[2] = (float)(p10 & 0xffu); tp[3] = (float)(p10 >> 8);
-                    tp[4] = (float)(p01 & 0xffu); tp[5] = (float)(p01 >> 8); tp[6] = (float)(p11 & 0xffu); tp[7] = (float)(p11 >> 8);
-                } else {
-                    const uint16_t *b = reinterpret_cast<const uint16_t *>(V.data) + ((uint64_t)brick * 729u + local);
-                    const uint32_t p00 = *reinterpret_cast<const u32_unaligned *>(b), p10 = *reinterpret_cast<const u32_unaligned *>(b + 9);
-                    const uint32_t p01 = *reinterpret_cast<const u32_unaligned *>(b + 81), p11 = *reinterpret_cast<const u32_unaligned *>(b + 90);
-                    tp[0] = h2f(p00 & 0xffffu); tp[1] = h2f(p00 >> 16); tp[2] = h2f(p10 & 0xffffu); tp[3] = h2f(p10 >> 16);
-                    tp[4] = h2f(p01 & 0xffffu); tp[5] = h2f(p01 >> 16); tp[6] = h2f(p11 & 0xffffu); tp[7] = h2f(p11 >> 16);
-                }
-                c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
-                c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
-            } else {
-                int x0 = clampi(ix, 0, mx), x1 = clampi(ix + (ix < 0x7fffffff), 0, mx);
-                int y0 = clampi(iy, 0, my), y1 = clampi(iy + (iy < 0x7fffffff), 0, my);
-                int z0 = clampi(iz, 0, mz), z1 = clampi(iz + (iz < 0x7fffffff), 0, mz);
-                size_t sy_ = V.nx, sz_ = (size_t)V.nx * V.ny;
-                size_t r00 = y0 * sy_ + z0 * sz_, r10 = y1 * sy_ + z0 * sz_;
-                size_t r01 = y0 * sy_ + z1 * sz_, r11 = y1 * sy_ + z1 * sz_;
-                float tp[8];
-                if (VOL == VOL_LINEAR_U8) {
-                    const uint8_t *v = reinterpret_cast<const uint8_t *>(V.data);
-                    tp[0] = (float)v[r00 + x0]; tp[1] = (float)v[r00 + x1]; tp[2] = (float)v[r10 + x0]; tp[3] = (float)v[r10 + x1];
-                    tp[4] = (float)v[r01 + x0]; tp[5] = (float)v[r01 + x1]; tp[6] = (float)v[r11 + x0]; tp[7] = (float)v[r11 + x1];
-                } else {
-                    const uint16_t *v = reinterpret_cast<const uint16_t *>(V.data);
-                    tp[0] = h2f(v[r00 + x0]); tp[1] = h2f(v[r00 + x1]); tp[2] = h2f(v[r10 + x0]); tp[3] = h2f(v[r10 + x1]);
-                    tp[4] = h2f(v[r01 + x0]); tp[5] = h2f(v[r01 + x1]); tp[6] = h2f(v[r11 + x0]); tp[7] = h2f(v[r11 + x1]);
-                }
-                c00 = fmaf(fx, tp[1] - tp[0], tp[0]); c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
-                c01 = fmaf(fx, tp[5] - tp[4], tp[4]); c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
-            }
-            float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
-            float r = fmaf(fz, c1 - c0, c0);
-            if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) r = r * (1.0f / 255.0f);
-            const float a = transfer_alpha(r);
-            // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
-            constexpr double kk = 6.28318 / 6.283185307179586476925;
-            constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
-            constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
-            const float cr = __builtin_amdgcn_cosf(a * pc0);
-            const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
-            const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
-            if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
-            const float w = (1.0f - A) * a;  // :112-114
-            Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
-            A = A + w;
-            px = px + sx; py = py + sy; pz = pz + sz;  // :118
-            t = t + dt;
-        }
+        RayState r;
+        r.t = t0; r.t1 = t1; r.dt = dt;
+        r.px = px; r.py = py; r.pz = pz; r.sx = sx; r.sy = sy; r.sz = sz;
+        r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
+        r.out = (uint32_t)pm.out_index;
+        march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs);
+        A = r.A; Gr = r.Gr; Gg = r.Gg; Gb = r.Gb;
         Cr = linear_to_srgb(fmaf(0.5f, Gr, 0.5f * A));  // :121-123
         Cg = linear_to_srgb(fmaf(0.5f, Gg, 0.5f * A));
         Cb = linear_to_srgb(fmaf(0.5f, Gb, 0.5f * A));
     }
     store_pixel<OUT>(L.out, pm.out_index, Cr, Cg, Cb, 1.0f);
     if (COUNT) {
-        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 1u) ? cs.n_look : cs.n_iter;
         if (L.counters) {
-            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
-            atomicAdd(&L.counters[1], (unsigned long long)n_samp);
-            atomicAdd(&L.counters[2], (unsigned long long)w_outer);
-            atomicAdd(&L.counters[3], (unsigned long long)w_inner);
-            atomicAdd(&L.counters[4], (unsigned long long)w_sample);
-            atomicAdd(&L.counters[5], (unsigned long long)n_look);
+            atomicAdd(&L.counters[0], (unsigned long long)cs.n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)cs.n_samp);
+            atomicAdd(&L.counters[2], (unsigned long long)cs.w_outer);
+            atomicAdd(&L.counters[3], (unsigned long long)cs.w_inner);
+            atomicAdd(&L.counters[4], (unsigned long long)cs.w_sample);
+            atomicAdd(&L.counters[5], (unsigned long long)cs.n_look);
         }
         if (L.trace) {  // stamps leave only through this debug buffer
             unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
@@ -456,7 +491,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             L.trace[4 * (size_t)lb + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
             // wave-level work: march-loop trips | skip-walk trips << 20 | sample executions << 40
-            atomicAdd(&L.trace[4 * (size_t)lb + 3], (unsigned long long)w_outer | ((unsigned long long)w_inner << 20) | ((unsigned long long)w_sample << 40));
+            atomicAdd(&L.trace[4 * (size_t)lb + 3], (unsigned long long)cs.w_outer | ((unsigned long long)cs.w_inner << 20) | ((unsigned long long)cs.w_sample << 40));
         }
     }
 }
