@@ -40,6 +40,13 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
         img = ctx.read_backbuffer()
         steps = ctx.read_steps() if want_steps else None
         counts = ctx.step_counts() if want_steps else None
+        if want_steps:
+            # the production (uninstrumented) kernel must reproduce the instrumented frame bit for bit
+            V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+            V.RaycastPipeline(pipe.mode, dt_scale=dt, flags=flags).record(ctx, tile)
+            again = ctx.read_backbuffer()
+            if tile is None:
+                assert (again.view(np.uint8) == img.view(np.uint8)).all(), "production path differs from the instrumented one"
         return img, steps, counts
     finally:
         ctx.close()
