@@ -28,5 +28,11 @@ with torch.cuda.stream(stream):
         t_cpu2 = time.perf_counter() - t0
         ctx.sync(); t_all2 = time.perf_counter() - t0
         print(f"{W}x{H}: submit() CPU {t_cpu / K * 1e6:.1f} us/frame, end-to-end {t_all / K * 1e6:.1f} us/frame | plain record CPU {t_cpu2 / K * 1e6:.1f}, end-to-end {t_all2 / K * 1e6:.1f}")
+        if W == 1920:
+            import cProfile, pstats
+            pr = cProfile.Profile(); pr.enable()
+            for k in range(500): tpr.submit(k)
+            pr.disable(); tpr.flush(); torch.cuda.synchronize()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
         ctx.close()
 dist.destroy_process_group()

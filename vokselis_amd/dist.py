@@ -63,14 +63,20 @@ class FrameGather:
         self.gathered = None
         if self.rank == root:
             self.gathered = [torch.zeros((self.world,) + shape, dtype=channels_dtype, device=device) for _ in range(2)]
+        self._views = {}  # (buffer, n_slots) -> (send view, [recv views]): slicing tensors costs microseconds per frame
 
     def start(self, k: int, n_slots: int | None = None):
         """Launch the gather of the first `n_slots` slots of compact[k % 2] (async); returns the work
         handle.  Slots beyond the active ones hold nothing worth moving (`Context.partition_active`)."""
         n = self.slots if n_slots is None else min(n_slots, self.slots)
-        buf = self.compact[k % 2][:n]
+        key = (k % 2, n)
+        v = self._views.get(key)
+        if v is None:
+            buf = self.compact[k % 2][:n]
+            out = [self.gathered[k % 2][r, :n] for r in range(self.world)] if self.rank == self.root else None
+            v = self._views[key] = (buf, out)
+        buf, out = v
         if self.rank == self.root:
-            out = [self.gathered[k % 2][r, :n] for r in range(self.world)]
             return self.dist.gather(buf, gather_list=out, dst=self.root, group=self.group, async_op=True)
         return self.dist.gather(buf, dst=self.root, group=self.group, async_op=True)
 
@@ -89,6 +95,7 @@ class TileParallelRenderer:
         self.fg = FrameGather(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group)
         assert self.fg.slots == partition_slots(bb.width, bb.height, tile_size, self.fg.world)
         self._pending = None  # (frame index, work) whose un-tile is still owed
+        self._active, self._active_key = None, None
 
     @property
     def is_root(self) -> bool:
@@ -98,7 +105,10 @@ class TileParallelRenderer:
         """Frame k: march this rank's tiles, start their gather; finish frame k-1 on the root."""
         fg = self.fg
         self.pipe.record_partition(self.ctx, fg.ts, fg.rank, fg.world, fg.compact[k % 2].data_ptr())
-        _, n_slots = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)  # cached per camera in the library
+        if self._active_key != id(self.ctx) or self.ctx.camera.updated or self._active is None:
+            self._active = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)[1]  # per camera; cached in the library too
+            self._active_key = id(self.ctx)
+        n_slots = self._active
         if n_slots == 0:
             self._finish_pending()
             self._pending = (k, None)
