@@ -479,12 +479,15 @@ int vk_backbuffer_clear(vk_ctx *ctx) {
 template <int VOL, bool SKIP, bool SAFE>
 static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+    // the fast path of the cell layouts keeps its per-axis index tables in LDS (vk_kernels.hpp: fill_cell_luts)
+    constexpr bool lut = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16) && !SAFE;
+    const uint32_t lds = lut ? cell_lut_bytes(V.nx, V.ny, V.nz) : 0u;
     if (f16) {
-        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, true>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, false>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     } else {
-        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, true>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA32F, false>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     }
 }
 
@@ -713,16 +716,17 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         // Skipping costs a distance lookup per iteration; it only pays when there is something to skip.
         // Default: on iff >= 10 % of the cells are exactly transparent (fog volumes: off).
         const bool skip = !(flags & VK_RENDER_NO_SKIP) && ((flags & VK_RENDER_FORCE_SKIP) || ctx->empty_fraction >= 0.10);
-        // SAFE=false (no per-axis clamps, 32-bit offsets) only when both are provably harmless:
-        // the cell array is < 2 GiB, and the camera is near enough that the accumulated position
-        // stays within 0.5/n of the box (|p error| <= ~64 ulp(reach) << 0.5/n).
+        // SAFE=false (no per-axis clamps, 32-bit offsets, index tables in LDS) only when provably
+        // harmless: the cell array is < 4 GiB, the tables fit a modest LDS budget, and the camera is
+        // near enough that the accumulated position stays within 0.5/n of the box
+        // (|p error| <= ~64 ulp(reach) << 0.5/n).
         bool safe = true;
         {
             const float *e = ctx->camera;
             float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
             float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
             float ulp = std::nextafter(reach, 2.0f * reach) - reach;
-            if (V.max_off + 16 < (1ll << 31) && 64 * (int64_t)ctx->nbx * ctx->nby < (1 << 23) && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
+            if (V.max_off + 16 < (1ll << 32) && cell_lut_bytes(ctx->nx, ctx->ny, ctx->nz) <= 16384u && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
         }
         switch (ctx->vol_kind) {
             case VOL_P8: launch_packed<VOL_P8>(ctx, L, V, grid, count, skip, safe); break;

@@ -235,6 +235,76 @@ __device__ __forceinline__ bool wave_leader() {
     return (int)(threadIdx.x & 63u) == __ffsll((unsigned long long)__ballot(1)) - 1;
 }
 
+// ---- per-axis cell-index tables (LDS) -----------------------------------------------------------
+// Cell with low-corner voxel i (i in [-1, n-1]) lives in physical brick (i >> 2) + 1 at in-brick
+// position i & 3, so its index splits per axis:
+//   Tx[i] = 64*((i>>2)+1) + (i&3),  Ty[i] = 64*nbx*((i>>2)+1) + 4*(i&3),  Tz[i] = 64*nbx*nby*((i>>2)+1) + 16*(i&3)
+// Each table has n + 3 entries, entry e = i + 2 for i in [-2, n]; the two outer entries repeat their
+// neighbours (clamp), so a position one step outside the box -- the prefetch of march_stream --
+// still reads a real entry.  The three tables are stored back to back.  `shift` pre-scales the
+// entries to byte offsets when no per-cell side table is read.
+__host__ __device__ __forceinline__ uint32_t cell_lut_bytes(uint32_t nx, uint32_t ny, uint32_t nz) { return (nx + ny + nz + 9u) * 4u; }
+
+__device__ __forceinline__ void fill_cell_luts(const VolumeDesc &V, uint32_t *lut, uint32_t lane, uint32_t shift) {
+    const uint32_t n0 = V.nx + 3u, n1 = V.ny + 3u, n2 = V.nz + 3u, total = n0 + n1 + n2;
+    for (uint32_t e = lane; e < total; e += 64u) {
+        uint32_t j = e, n = n0, brick_mul = 64u, cell_mul = 1u;
+        if (e >= n0 + n1) { j = e - n0 - n1; n = n2; brick_mul = 64u * V.nbx * V.nby; cell_mul = 16u; }
+        else if (e >= n0) { j = e - n0; n = n1; brick_mul = 64u * V.nbx; cell_mul = 4u; }
+        const uint32_t c = min(max(j, 1u), n - 2u) - 1u;  // cell coordinate i + 1 in [0, n_vox]
+        lut[e] = (brick_mul * ((c + 3u) >> 2) + cell_mul * ((c + 3u) & 3u)) << shift;
+    }
+}
+
+// Bounds-checked view of the cell array for the fast path (< 4 GiB): a raw buffer resource, so an
+// offset outside the array reads zeros instead of faulting (memory-safety net; never hit by a valid ray).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cell_buffer(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
+}
+
+// x-lerps of one cell: c00, c10, c01, c11 (the four x edges of the footprint)
+template <int VOL>
+struct CellBits { u32x4_t v; };
+template <>
+struct CellBits<VOL_P8> { u32x2_t v; };
+
+// PIN: mark the load volatile (aux bit 31: compiler-only, nothing changes in the encoding) so that it
+// is issued where it is written -- a prefetch must not be sunk behind the loop's exit branch.
+template <int VOL, bool PIN = false>
+__device__ __forceinline__ CellBits<VOL> load_cell(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    constexpr int aux = PIN ? (int)0x80000000u : 0;
+    CellBits<VOL> c;
+    if constexpr (VOL == VOL_P8) c.v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, aux);
+    else c.v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, aux);
+    return c;
+}
+
+template <int VOL>
+__device__ __forceinline__ void xlerp_cell(const CellBits<VOL> &cb, float fx, float &c00, float &c10, float &c01, float &c11) {
+    if constexpr (VOL == VOL_P8) {
+        const uint32_t lo = cb.v.x, hi = cb.v.y;
+        float t0_ = (float)(lo & 0xffu), t1_ = (float)((lo >> 8) & 0xffu), t2_ = (float)((lo >> 16) & 0xffu), t3_ = (float)(lo >> 24);
+        float t4_ = (float)(hi & 0xffu), t5_ = (float)((hi >> 8) & 0xffu), t6_ = (float)((hi >> 16) & 0xffu), t7_ = (float)(hi >> 24);
+        c00 = fmaf(fx, t1_ - t0_, t0_); c10 = fmaf(fx, t3_ - t2_, t2_);
+        c01 = fmaf(fx, t5_ - t4_, t4_); c11 = fmaf(fx, t7_ - t6_, t6_);
+    } else {
+        union { u32x4_t u; half2_t h[4]; } c;
+        c.u = cb.v;
+        if constexpr (VOL == VOL_P16) {
+            // (tap, delta) pairs: delta = t1 - t0 is exact in f16 for u8 data -> v_fma_mix_f32
+            c00 = fmaf(fx, (float)c.h[0].y, (float)c.h[0].x); c10 = fmaf(fx, (float)c.h[1].y, (float)c.h[1].x);
+            c01 = fmaf(fx, (float)c.h[2].y, (float)c.h[2].x); c11 = fmaf(fx, (float)c.h[3].y, (float)c.h[3].x);
+        } else {
+            float a0 = (float)c.h[0].x, a1 = (float)c.h[0].y, a2 = (float)c.h[1].x, a3 = (float)c.h[1].y;
+            float a4 = (float)c.h[2].x, a5 = (float)c.h[2].y, a6 = (float)c.h[3].x, a7 = (float)c.h[3].y;
+            c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
+            c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
+        }
+    }
+}
+
 // ---- the march, resumable ---------------------------------------------------------------------
 // Everything a ray needs to continue: the accumulators of the reference loop (t, p, alpha, colour
 // sums), its per-ray constants and where its pixel goes.  64 bytes.
@@ -252,8 +322,16 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 // Runs at most `budget` trips of the reference loop (raycast_naive.wgsl:101-119) on the state and
 // returns whether the ray is still alive.  State in, state out: a ray marched in several pieces
 // goes through exactly the same f32 operations as one marched in one go.
-template <int VOL, bool SKIP, bool SAFE, bool COUNT>
-__device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs) {
+//
+// SAFE=false (the fast path of the PACKED layouts) looks the cell index up instead of computing it:
+// idx = Tx[ix] + Ty[iy] + Tz[iz] with three small per-axis tables in LDS (`lut`, filled by the kernel:
+// see fill_cell_luts).  Three ds_read_b32 (not VALU) + one v_add3 replace the 14 integer VALU
+// instructions of the closed form -- the loop is VALU-issue bound.  Every table entry is a valid
+// non-negative partial index and LDS reads outside the allocation return 0, so any combination stays
+// inside the cell array: no clamp.
+template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false>
+__device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs,
+                                      const uint32_t *lut = nullptr) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
     constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
     float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
@@ -267,21 +345,35 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     // down), minus a 0.02-cell margin that covers the rounding of the accumulated position
     // (<= 1e-3 cells); folded into two fmas: r_i = f_i * ska_i + (d * idu_i + skb_i).
     float idux = 0.f, iduy = 0.f, iduz = 0.f, skax = 0.f, skay = 0.f, skaz = 0.f, skbx = 0.f, skby = 0.f, skbz = 0.f;
-    float inv_dt = 0.f;
     if (SKIP) {
-        inv_dt = __builtin_amdgcn_rcpf(dt);  // only bounds a skip length (2 steps of slack below)
-        idux = __builtin_amdgcn_rcpf(fabsf(sx) * fnx); iduy = __builtin_amdgcn_rcpf(fabsf(sy) * fny); iduz = __builtin_amdgcn_rcpf(fabsf(sz) * fnz);
-        skax = sx >= 0.0f ? -idux : idux; skay = sy >= 0.0f ? -iduy : iduy; skaz = sz >= 0.0f ? -iduz : iduz;
-        skbx = (sx >= 0.0f ? -0.02f : -1.02f) * idux; skby = (sy >= 0.0f ? -0.02f : -1.02f) * iduy;
-        skbz = (sz >= 0.0f ? -0.02f : -1.02f) * iduz;
+        // rcp (1 ulp) is enough: these constants only bound a skip length, with the margins below.
+        const float dux = fabsf(sx) * fnx, duy = fabsf(sy) * fny, duz = fabsf(sz) * fnz;  // cells per step
+        idux = __builtin_amdgcn_rcpf(dux); iduy = __builtin_amdgcn_rcpf(duy); iduz = __builtin_amdgcn_rcpf(duz);
+        // Position margin, in cells: a walk crosses at most kDistRadius + 1 cells of its fastest axis,
+        // i.e. n <= 25 / max(du) steps, each adding <= 2^-25 of rounding to a coordinate in [0, 1]
+        // (x n_i cells); doubled, plus 0.01 for the rounding of u itself.
+        const float n_walk = (float)(kDistRadius + 1) * __builtin_amdgcn_rcpf(fmaxf(dux, fmaxf(duy, duz)));
+        const float mg = fmaf(n_walk * 0x1p-24f, fmaxf(fnx, fmaxf(fny, fnz)), 0.01f);
+        // Step margin: the walk below stops on the accumulated t; n additions drift by <= n * 2^-24 * t1,
+        // i.e. a fraction e = 2^-24 * t1 / dt of the walk length (x4 for the fma and rcp roundings).
+        const float e = fminf(0x1p-22f * t1 * __builtin_amdgcn_rcpf(dt), 1.0f);
+        const float sc = 1.0f - e, cst = -(e + 0.01f);
+        skax = (sx >= 0.0f ? -idux : idux) * sc; skay = (sy >= 0.0f ? -iduy : iduy) * sc; skaz = (sz >= 0.0f ? -iduz : iduz) * sc;
+        skbx = fmaf((sx >= 0.0f ? -mg : -1.0f - mg) * idux, sc, cst);
+        skby = fmaf((sy >= 0.0f ? -mg : -1.0f - mg) * iduy, sc, cst);
+        skbz = fmaf((sz >= 0.0f ? -mg : -1.0f - mg) * iduz, sc, cst);
+        idux *= sc; iduy *= sc; iduz *= sc;
     }
+    const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
+    const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, SAFE ? 0u : (uint32_t)V.max_off + (1u << V.sh_x));
+    const float t1q = __builtin_canonicalizef(t1);  // known-quiet copy: keeps a per-trip canonicalise out of the skip branch
 
     // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
     // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
     // changes nothing observable.
     uint32_t trip = 0;  // wave-uniform: the active lanes of a wave entered the loop together
-    while (t < t1 && A < 0.95f && trip < budget) {
-        ++trip;
+    while (t < t1 && A < 0.95f && (!BOUNDED || trip < budget)) {
+        if (BOUNDED) ++trip;
         if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
         int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
@@ -290,8 +382,8 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         if (PACKED) {
             if (SAFE) { ix = med3_i32(ix, -1, mx); iy = med3_i32(iy, -1, my); iz = med3_i32(iz, -1, mz); }
             const int bx = ix >> 2, by = iy >> 2, bz = iz >> 2;
-            const char *cptr;
-            uint32_t d = 0;
+            const char *cptr = nullptr;
+            uint32_t d = 0, coff = 0;
             if (SAFE) {
                 int64_t off = (int64_t)bz * (int64_t)V.kz + (int64_t)(by * (int)V.ky + bx * (int)V.kx) +
                               (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
@@ -299,56 +391,51 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 cptr = reinterpret_cast<const char *>(V.data) + off;
                 if (SKIP) d = V.dist[off >> V.sh_x];
             } else {
-                // cell index, affine in (i, i >> 2)
-                const uint32_t acc = (uint32_t)(bz * V.ciz + by * V.ciy + bx * 60 + (iz << 4) + (iy << 2) + ix + V.ci0);
-                const uint32_t idx = min(acc, V.max_idx);  // memory-safety net; never binds for valid rays
-                cptr = reinterpret_cast<const char *>(V.data) + (uint32_t)(idx << V.sh_x);  // < 2 GiB: SGPR base + 32-bit offset
+                // cell index (SKIP) / cell byte offset (!SKIP) from the per-axis tables; entry i + 2 is voxel i
+                const uint32_t idx = lut[ix + 2] + luty[iy + 2] + lutz[iz + 2];
+                coff = SKIP ? (uint32_t)(idx << V.sh_x) : idx;
                 if (SKIP) d = V.dist[idx];
             }
             if (SKIP && d != 0) {
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
                 // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
-                // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margin.
+                // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margins:
+                // j < r = min_i r_i, r_i = f_i * ska_i + (d * idu_i + skb_i).
                 const float fd = (float)d;
                 const float rx = fmaf(fx, skax, fmaf(fd, idux, skbx));
                 const float ry = fmaf(fy, skay, fmaf(fd, iduy, skby));
                 const float rz = fmaf(fz, skaz, fmaf(fd, iduz, skbz));
-                // ... and never past the ray's end: iterations j <= (t1 - t)/dt - 2 certainly see
-                // t < t1, so the walk needs no float compare; the last couple of iterations of a
-                // ray fall back to single steps, where the loop's own `t < t1` test decides.
-                const float rend = fmaf(t1 - t, inv_dt, -2.0f);
-                // float -> u32 conversion saturates negatives and NaN to 0; +1: the current sample is
-                // always skippable (its cell is empty)
-                uint32_t k = cvt_u32_sat(fminf(fminf(rx, rend), fminf(ry, rz))) + 1u;
-                do {  // skipped iterations: body contributes exactly +0 (alpha == 0)
+                // The walk advances the reference loop's own accumulators (p += s, t += dt: the same
+                // f32 additions in the same order) while t < tstop.  tstop <= t1, so every skipped
+                // iteration passed the reference's `t < t1` test on the very same t; and t_j < tstop
+                // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
+                const float tstop = fminf(fmaf(fminf(fminf(rx, ry), rz), dt, t), t1q);
+                const float tstop2 = fmaf(-1.5f, dt, tstop);  // t < tstop2  =>  t + dt < tstop as well
+                px = px + sx; py = py + sy; pz = pz + sz;
+                t = t + dt;
+                if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
+                while (t < tstop2) {  // two skipped iterations per trip
                     px = px + sx; py = py + sy; pz = pz + sz;
                     t = t + dt;
-                    if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
-                } while (--k > 0);
+                    px = px + sx; py = py + sy; pz = pz + sz;
+                    t = t + dt;
+                    if (COUNT) { n_iter += 2; if (wave_leader()) w_inner++; }
+                }
+                if (t < tstop) {
+                    px = px + sx; py = py + sy; pz = pz + sz;
+                    t = t + dt;
+                    if (COUNT) { n_iter++; }
+                }
                 continue;
             }
-            if (VOL == VOL_P8) {
-                uint2 c = *reinterpret_cast<const uint2 *>(cptr);
-                float t0_ = (float)(c.x & 0xffu), t1_ = (float)((c.x >> 8) & 0xffu);
-                float t2_ = (float)((c.x >> 16) & 0xffu), t3_ = (float)(c.x >> 24);
-                float t4_ = (float)(c.y & 0xffu), t5_ = (float)((c.y >> 8) & 0xffu);
-                float t6_ = (float)((c.y >> 16) & 0xffu), t7_ = (float)(c.y >> 24);
-                c00 = fmaf(fx, t1_ - t0_, t0_); c10 = fmaf(fx, t3_ - t2_, t2_);
-                c01 = fmaf(fx, t5_ - t4_, t4_); c11 = fmaf(fx, t7_ - t6_, t6_);
-            } else if (VOL == VOL_P16) {
-                union { uint4 u; half2_t h[4]; } c;
-                c.u = *reinterpret_cast<const uint4 *>(cptr);
-                // (tap, delta) pairs: delta = t1 - t0 is exact in f16 for u8 data -> v_fma_mix_f32
-                c00 = fmaf(fx, (float)c.h[0].y, (float)c.h[0].x); c10 = fmaf(fx, (float)c.h[1].y, (float)c.h[1].x);
-                c01 = fmaf(fx, (float)c.h[2].y, (float)c.h[2].x); c11 = fmaf(fx, (float)c.h[3].y, (float)c.h[3].x);
+            CellBits<VOL> cb;
+            if (SAFE) {
+                if constexpr (VOL == VOL_P8) { const uint2 c = *reinterpret_cast<const uint2 *>(cptr); cb.v.x = c.x; cb.v.y = c.y; }
+                else { const uint4 c = *reinterpret_cast<const uint4 *>(cptr); cb.v.x = c.x; cb.v.y = c.y; cb.v.z = c.z; cb.v.w = c.w; }
             } else {
-                union { uint4 u; half2_t h[4]; } c;
-                c.u = *reinterpret_cast<const uint4 *>(cptr);
-                float a0 = (float)c.h[0].x, a1 = (float)c.h[0].y, a2 = (float)c.h[1].x, a3 = (float)c.h[1].y;
-                float a4 = (float)c.h[2].x, a5 = (float)c.h[2].y, a6 = (float)c.h[3].x, a7 = (float)c.h[3].y;
-                c00 = fmaf(fx, a1 - a0, a0); c10 = fmaf(fx, a3 - a2, a2);
-                c01 = fmaf(fx, a5 - a4, a4); c11 = fmaf(fx, a7 - a6, a6);
+                cb = load_cell<VOL>(cells, coff);
             }
+            xlerp_cell<VOL>(cb, fx, c00, c10, c01, c11);
         } else if (BRICK9) {
             // cell coords c = i + 1 in [0, n]; brick c >> 3, local c & 7; the taps sit at local
             // (l, l+1) per axis of the 9^3 brick: offsets {0,1} + {0,9} + {0,81} from one base
@@ -415,6 +502,59 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     return t < t1 && A < 0.95f;
 }
 
+// The same loop for the fast path without skipping (every trip samples), software-pipelined: the
+// position is advanced first and the NEXT trip's cell is requested before this trip's sample is
+// evaluated, so the fetch latency overlaps the ~40 VALU instructions of a sample instead of adding
+// to them -- it is the lone heavy waves at the tail of a frame that set the frame time.  The f32
+// operations on t, p, A and the colour sums are those of march(), in the same order per variable.
+// The request one step past the ray's end reads a real (clamped) table entry and is never used.
+template <int VOL, bool COUNT>
+__device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, Census &cs, const uint32_t *lut) {
+    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+    const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
+    const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, (uint32_t)V.max_off + (1u << V.sh_x));
+    if (!(t < t1 && A < 0.95f)) return;
+    float fx, fy, fz;
+    CellBits<VOL> cur;
+    {
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        cur = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
+    }
+    CellBits<VOL> nxt;
+    for (;;) {
+        if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; if (wave_leader()) { cs.w_outer++; cs.w_sample++; } }
+        px = px + sx; py = py + sy; pz = pz + sz;  // :118
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        nxt = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
+        float c00, c10, c01, c11;
+        xlerp_cell<VOL>(cur, fx, c00, c10, c01, c11);
+        float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
+        float v = fmaf(fz, c1 - c0, c0);
+        if (VOL == VOL_P8 || VOL == VOL_P16) v = v * (1.0f / 255.0f);
+        const float a = transfer_alpha(v);
+        constexpr double kk = 6.28318 / 6.283185307179586476925;
+        constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+        constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+        const float cr = __builtin_amdgcn_cosf(a * pc0);
+        const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+        const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+        const float w = (1.0f - A) * a;  // :112-114
+        Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
+        A = A + w;
+        t = t + dt;
+        if (!(t < t1 && A < 0.95f)) break;
+        cur = nxt;
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+    }
+    // The last request is consumed here, on the exit path too: with a use on both sides of the exit
+    // branch the compiler cannot sink the request behind it (which would undo the pipelining).
+    asm volatile("" ::"v"(nxt.v));
+    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+}
+
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
@@ -424,17 +564,24 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     unsigned long long t_start = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
     const PixelMap pm = map_pixel(L, lb, lane);
-    if (!pm.valid) return;
     {
         // Screen-space cull (wave-uniform): an 8x8 block wholly outside the projected cube's bounding
         // rectangle (host-computed, padded) holds only misses: clear colour, no ray set-up.
         const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
         if (bx0 + 8 <= L.cull_x0 || bx0 >= L.cull_x1 || by0 + 8 <= L.cull_y0 || by0 >= L.cull_y1) {
+            if (!pm.valid) return;
             store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
             return;
         }
     }
+    constexpr bool USE_LUT = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16) && !SAFE;
+    extern __shared__ uint32_t cell_lut[];
+    if (USE_LUT) {  // all 64 lanes are still here
+        fill_cell_luts(V, cell_lut, lane, SKIP ? 0u : V.sh_x);
+        __syncthreads();
+    }
+    if (!pm.valid) return;
 
     // --- ray: SURVEY A.1 step 1 (replaces vs_main + rasteriser) ---
     float fxp = (float)pm.x + 0.5f, fyp = (float)pm.y + 0.5f;
@@ -466,7 +613,8 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.px = px; r.py = py; r.pz = pz; r.sx = sx; r.sy = sy; r.sz = sz;
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
-        march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs);
+        if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
+        else march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
         A = r.A; Gr = r.Gr; Gg = r.Gg; Gb = r.Gb;
         Cr = linear_to_srgb(fmaf(0.5f, Gr, 0.5f * A));  // :121-123
         Cg = linear_to_srgb(fmaf(0.5f, Gg, 0.5f * A));
