@@ -241,7 +241,11 @@ def test_cameras_dims_and_dt(V, O):
                                      ((33, 17, 65), (2.0, 1.2, 0.3, (0.5, 0.5, 0.5), 0.75), 60, 80, 2.0),
                                      ((64, 64, 64), (1.5, 0.0, 0.0, (0.5, 0.5, 0.5), 1.0), 64, 64, 1.0),
                                      ((1, 1, 1), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 32, 32, 0.5),
-                                     ((2, 3, 5), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 32, 32, 0.1)]:
+                                     ((2, 3, 5), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 32, 32, 0.1),
+                                     # very short and very long steps: the skip walk's rounding margins scale with both
+                                     ((64, 64, 64), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 40, 40, 0.02),
+                                     ((128, 96, 64), (1.3, 0.4, 2.0, (0.5, 0.5, 0.5), 1.0), 48, 48, 0.013),
+                                     ((48, 48, 48), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0), 48, 48, 3.5)]:
         nx, ny, nz = dims
         vol = (O.volume_standin_u8(dims, seed=5) if min(dims) >= 17 else rng.integers(0, 256, (nz, ny, nx)).astype(np.uint8))
         cam = O.camera_blob(*cam_args)

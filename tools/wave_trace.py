@@ -48,7 +48,7 @@ print("distinct SIMDs seen", len(uk), "xcc values", np.unique(xcc), "se", np.uni
 print("per-SIMD summed wave time: mean %.0f  p50 %.0f  p90 %.0f  max %.0f   (frame span %.0f)" % (load.mean(), np.percentile(load, 50), np.percentile(load, 90), load.max(), en.max()))
 print("heavy (top-10%%) waves per SIMD: mean %.2f max %d  hist %s" % (heavy.mean(), heavy.max(), np.bincount(heavy.astype(int)).tolist()))
 wo = (work & np.uint64(0xfffff)).astype(np.float64); wi = ((work >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.float64); ws = (work >> np.uint64(40)).astype(np.float64)
-est = wo * 35 + wi * 7 + ws * 35          # issue-slot estimate per wave
+est = wo * 27 + wi * 5 + ws * 33          # issue-slot estimate per wave
 wl = np.bincount(inv, weights=est)
 print("per-SIMD estimated work (issue slots): mean %.0f p50 %.0f p90 %.0f max %.0f  -> max/mean %.2f" % (wl.mean(), np.percentile(wl, 50), np.percentile(wl, 90), wl.max(), wl.max() / wl.mean()))
 cu_key = key // 4; ucu, icu = np.unique(cu_key, return_inverse=True); wcu = np.bincount(icu, weights=est)

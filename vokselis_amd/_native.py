@@ -16,6 +16,7 @@ MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
 LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED = 0, 1, 2, 3, 4
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
+RENDER_DEBUG_TRIPS = 16
 GEN_FOG, GEN_BONSAI_STANDIN = 0, 1
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)

@@ -259,36 +259,61 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
     if (n_bricks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for 32-bit brick indices");
     if (n_cells >= (1ull << 32)) return fail(ctx, VK_ERR_UNSUPPORTED, "cell layouts hold < 2^32 cells (about 1600^3): use VK_LAYOUT_BRICKED or VK_LAYOUT_AUTO");
     HIP_TRY(ctx, hipMalloc(&ctx->vol, n_cells * cell_bytes));
-    uint8_t *tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&ctx->dist, n_cells));
-    HIP_TRY(ctx, hipMalloc(&tmp, n_cells));
-    ctx->vol_bytes = n_cells * cell_bytes + n_cells;
+    // scratch: occupancy map + two pass buffers
+    uint8_t *occ = nullptr, *tx = nullptr, *txy = nullptr;
+    auto drop_scratch = [&]() { (void)hipFree(occ); (void)hipFree(tx); (void)hipFree(txy); if (own_src) (void)hipFree(const_cast<void *>(d_src)); };
+    HIP_TRY(ctx, hipMalloc(&occ, n_cells));
+    if (hipMalloc(&tx, n_cells) != hipSuccess || hipMalloc(&txy, n_cells) != hipSuccess) { drop_scratch(); return fail(ctx, VK_ERR_HIP, "volume re-layout scratch allocation failed"); }
     ctx->vol_kind = kind;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counters + 7, 0, sizeof(unsigned long long), ctx->stream));
+    hipError_t e0 = hipMemsetAsync(ctx->counters + 7, 0, sizeof(unsigned long long), ctx->stream);
     const uint64_t pack_blocks64 = (n_cells + 255) / 256;
-    if (pack_blocks64 >= (1ull << 31)) { (void)hipFree(tmp); return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for one launch"); }
+    if (e0 != hipSuccess || pack_blocks64 >= (1ull << 31)) { drop_scratch(); return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for one launch"); }
     const uint32_t pack_blocks = (uint32_t)pack_blocks64;
     if (kind == VOL_PF16)
-        hipLaunchKernelGGL(pack_cells_kernel<VOL_PF16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_PF16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, occ, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
     else if (kind == VOL_P16)
-        hipLaunchKernelGGL(pack_cells_kernel<VOL_P16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_P16>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, occ, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
     else
-        hipLaunchKernelGGL(pack_cells_kernel<VOL_P8>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, ctx->dist, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 0, 0);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, tmp, ctx->dist, ctx->nbx, ctx->nby, ctx->nbz, 1, 0);
-    hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, ctx->dist, tmp, ctx->nbx, ctx->nby, ctx->nbz, 2, 1);
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { (void)hipFree(tmp); return fail(ctx, VK_ERR_HIP, std::string("volume re-layout launch: ") + hipGetErrorString(le)); }
-    hipError_t ce = hipMemcpyAsync(ctx->dist, tmp, n_cells, hipMemcpyDeviceToDevice, ctx->stream);
-    hipError_t se = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    if (own_src) { (void)hipFree(const_cast<void *>(d_src)); }
-    if (ce != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("dist copy: ") + hipGetErrorString(ce));
-    if (se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("volume re-layout: ") + hipGetErrorString(se));
+        hipLaunchKernelGGL(pack_cells_kernel<VOL_P8>, dim3(pack_blocks), dim3(256), 0, ctx->stream, d_src, ctx->vol, occ, nx, ny, nz, ctx->nbx, ctx->nby, n_cells, ctx->counters + 7);
     {
         unsigned long long ne = 0;
-        HIP_TRY(ctx, hipMemcpy(&ne, ctx->counters + 7, sizeof(ne), hipMemcpyDeviceToHost));
+        hipError_t le = hipGetLastError();
+        hipError_t ce = hipMemcpyAsync(&ne, ctx->counters + 7, sizeof(ne), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (le != hipSuccess || ce != hipSuccess || se != hipSuccess) {
+            drop_scratch();
+            return fail(ctx, VK_ERR_HIP, std::string("volume re-layout: ") + hipGetErrorString(le != hipSuccess ? le : (ce != hipSuccess ? ce : se)));
+        }
         ctx->empty_fraction = (double)ne / (double)n_cells;
+    }
+    // Distance maps.  Eight one-sided maps (one per ray octant) when skipping will be on by default
+    // (>= 10 % empty cells) and they stay <= 2 GiB; otherwise one isotropic map serves every octant.
+    const bool octants = ctx->empty_fraction >= 0.10 && n_cells <= (1ull << 28);
+    const uint64_t dist_bytes = octants ? 8 * n_cells : n_cells;
+    if (hipMalloc(&ctx->dist, dist_bytes) != hipSuccess) { drop_scratch(); return fail(ctx, VK_ERR_HIP, "distance map allocation failed"); }
+    ctx->vol_bytes = n_cells * cell_bytes + dist_bytes;
+    ctx->vdesc.dist_oct_stride = octants ? (uint32_t)n_cells : 0u;
+    auto pass = [&](const uint8_t *in, uint8_t *out, int axis, int dir, int last) {
+        hipLaunchKernelGGL(dist_pass_kernel, dim3(pack_blocks), dim3(256), 0, ctx->stream, in, out, ctx->nbx, ctx->nby, ctx->nbz, axis, dir, last);
+    };
+    if (octants) {
+        for (int ux = 0; ux < 2; ux++) {
+            pass(occ, tx, 0, ux ? 1 : -1, 0);
+            for (int uy = 0; uy < 2; uy++) {
+                pass(tx, txy, 1, uy ? 1 : -1, 0);
+                for (int uz = 0; uz < 2; uz++) pass(txy, ctx->dist + (size_t)(ux | (uy << 1) | (uz << 2)) * n_cells, 2, uz ? 1 : -1, 1);
+            }
+        }
+    } else {
+        pass(occ, tx, 0, 0, 0);
+        pass(tx, txy, 1, 0, 0);
+        pass(txy, ctx->dist, 2, 0, 1);
+    }
+    {
+        hipError_t le = hipGetLastError();
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        drop_scratch();
+        if (le != hipSuccess || se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("distance maps: ") + hipGetErrorString(le != hipSuccess ? le : se));
     }
     // addressing constants (vk_kernels.hpp: VolumeDesc)
     VolumeDesc &V = ctx->vdesc;

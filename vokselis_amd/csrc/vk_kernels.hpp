@@ -23,7 +23,10 @@ namespace vk {
 // so a wave's 8x8 ray bundle touches a handful of lines whatever the ray direction.  A u8 map in
 // the same cell order (one 64 B line per brick) holds each cell's Chebyshev distance, in cells,
 // to the nearest cell that has any tap above the transfer function's zero threshold (0 = this
-// cell contributes); it drives exact empty-space skipping.
+// cell contributes); it drives exact empty-space skipping.  There are eight such maps, one per
+// octant of ray directions: map o only looks at cells AHEAD of a ray of that octant (offset >= 0
+// on the axes it moves up, <= 0 on the others), so a ray leaving a surface skips at once instead of
+// creeping away from what is behind it.
 constexpr int kBrick = 4;
 constexpr int kBrickCells = 64;
 constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
@@ -40,7 +43,8 @@ enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 struct VolumeDesc {
     const void *data;     // cells (PACKED) or dense voxels (LINEAR); PAIR: density rgba16f
     const void *data2;    // PAIR: normals rgba16f
-    const uint8_t *dist;  // PACKED: per-cell distance map (same index as the cells)
+    const uint8_t *dist;  // PACKED: per-cell distance maps (same index as the cells), one per ray octant
+    uint32_t dist_oct_stride;  // cells between consecutive octant maps; 0: one isotropic map serves all octants
     uint32_t nx, ny, nz;  // voxel dims
     uint32_t nbx, nby, nbz;  // brick grid dims
     // byte offset of the cell with low-corner voxel (ix,iy,iz), b = i >> 2:
@@ -89,6 +93,10 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t b) {
     uint32_t group = b >> 9, r = b & 511u;
     return (group << 9) + ((r & 7u) << 6) + (r >> 3);
 }
+
+// (Dealing the tiles out SIMD by SIMD -- every SIMD one block from each of 8 tiles -- left the per-SIMD work
+// spread at max/mean 1.66: the spread is block-to-block variation inside tiles, not tile placement.
+// tools/experiments/simd_interleaved_block_order.patch)
 
 struct PixelMap {
     int32_t x, y;      // image coordinates
@@ -364,6 +372,8 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         skbz = fmaf((sz >= 0.0f ? -mg : -1.0f - mg) * iduz, sc, cst);
         idux *= sc; iduy *= sc; iduz *= sc;
     }
+    // this ray's octant selects its distance map (bit i: moving up on axis i, as in ska/skb above)
+    const uint32_t doff = SKIP ? ((sx >= 0.0f ? 1u : 0u) | (sy >= 0.0f ? 2u : 0u) | (sz >= 0.0f ? 4u : 0u)) * V.dist_oct_stride : 0u;
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, SAFE ? 0u : (uint32_t)V.max_off + (1u << V.sh_x));
     const float t1q = __builtin_canonicalizef(t1);  // known-quiet copy: keeps a per-trip canonicalise out of the skip branch
@@ -389,12 +399,12 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                               (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
                 off = off < 0 ? 0 : (off > (int64_t)V.max_off ? (int64_t)V.max_off : off);
                 cptr = reinterpret_cast<const char *>(V.data) + off;
-                if (SKIP) d = V.dist[off >> V.sh_x];
+                if (SKIP) d = V.dist[(uint64_t)(off >> V.sh_x) + doff];
             } else {
                 // cell index (SKIP) / cell byte offset (!SKIP) from the per-axis tables; entry i + 2 is voxel i
                 const uint32_t idx = lut[ix + 2] + luty[iy + 2] + lutz[iz + 2];
                 coff = SKIP ? (uint32_t)(idx << V.sh_x) : idx;
-                if (SKIP) d = V.dist[idx];
+                if (SKIP) d = V.dist[idx + doff];
             }
             if (SKIP && d != 0) {
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
@@ -517,22 +527,22 @@ __device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, C
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, (uint32_t)V.max_off + (1u << V.sh_x));
     if (!(t < t1 && A < 0.95f)) return;
     float fx, fy, fz;
-    CellBits<VOL> cur;
+    CellBits<VOL> c0, c1;  // two cell buffers, used alternately (no register copies between trips)
     {
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
-        cur = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
+        c0 = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
     }
-    CellBits<VOL> nxt;
-    for (;;) {
+    // one trip: request `nxt` for the advanced position, evaluate `cur`; returns whether the ray goes on
+    auto trip = [&](const CellBits<VOL> &cur, CellBits<VOL> &nxt) -> bool {
         if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; if (wave_leader()) { cs.w_outer++; cs.w_sample++; } }
         px = px + sx; py = py + sy; pz = pz + sz;  // :118
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
         nxt = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
         float c00, c10, c01, c11;
         xlerp_cell<VOL>(cur, fx, c00, c10, c01, c11);
-        float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
-        float v = fmaf(fz, c1 - c0, c0);
+        float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
+        float v = fmaf(fz, l1 - l0, l0);
         if (VOL == VOL_P8 || VOL == VOL_P16) v = v * (1.0f / 255.0f);
         const float a = transfer_alpha(v);
         constexpr double kk = 6.28318 / 6.283185307179586476925;
@@ -545,13 +555,16 @@ __device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, C
         Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
         A = A + w;
         t = t + dt;
-        if (!(t < t1 && A < 0.95f)) break;
-        cur = nxt;
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        return t < t1 && A < 0.95f;
+    };
+    for (;;) {
+        if (!trip(c0, c1)) break;
+        if (!trip(c1, c0)) break;
     }
-    // The last request is consumed here, on the exit path too: with a use on both sides of the exit
-    // branch the compiler cannot sink the request behind it (which would undo the pipelining).
-    asm volatile("" ::"v"(nxt.v));
+    // The last requests are consumed here, on the exit path too: with a use on both sides of the exit
+    // branch the compiler cannot sink a request behind it (which would undo the pipelining).
+    asm volatile("" ::"v"(c0.v), "v"(c1.v));
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
@@ -810,7 +823,8 @@ __global__ __launch_bounds__(256) void pack_bricks9_kernel(const void *__restric
 }
 
 // One separable pass of the Chebyshev (L-infinity) distance transform over the cells:
-// out(c) = min_j max(in(c + j*axis), |j|), |j| <= kDistRadius.  Outside the grid counts as empty.
+// out(c) = min_j max(in(c + j*axis), |j|), |j| <= kDistRadius, j restricted to j >= 0 (dir > 0),
+// j <= 0 (dir < 0) or unrestricted (dir == 0).  Outside the grid counts as empty.
 // Cells are addressed in their bricked storage order.
 __device__ __forceinline__ uint64_t cell_index(uint32_t x, uint32_t y, uint32_t z, uint32_t nbx, uint32_t nby) {
     uint64_t brick = ((uint64_t)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
@@ -818,7 +832,7 @@ __device__ __forceinline__ uint64_t cell_index(uint32_t x, uint32_t y, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                        uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int last) {
+                                                        uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int dir, int last) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t n = (uint64_t)nbx * nby * nbz * 64;
     if (id >= n) return;
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restric
     const int dim = (int)(axis == 0 ? nbx : (axis == 1 ? nby : nbz)) * 4;
     const int c0 = (int)c[axis];
     int best = in[id];
-    const int jlo = max(-kDistRadius, -c0), jhi = min(kDistRadius, dim - 1 - c0);
+    const int jlo = dir > 0 ? 0 : max(-kDistRadius, -c0), jhi = dir < 0 ? 0 : min(kDistRadius, dim - 1 - c0);
     for (int j = jlo; j <= jhi; j++) {
         const int aj = j < 0 ? -j : j;
         if (aj >= best) continue;  // cannot improve
