@@ -27,6 +27,7 @@ struct vk_ctx {
     // volume
     void *vol = nullptr, *vol2 = nullptr;  // cells / dense voxels / pair
     uint8_t *dist = nullptr;
+    uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
     size_t vol_bytes = 0;
     uint32_t nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     int format = -1, layout = 0;
@@ -132,8 +133,10 @@ static void free_volume(vk_ctx *ctx) {
     if (ctx->vol) (void)hipFree(ctx->vol);
     if (ctx->vol2) (void)hipFree(ctx->vol2);
     if (ctx->dist) (void)hipFree(ctx->dist);
+    if (ctx->lut) (void)hipFree(ctx->lut);
     ctx->vol = ctx->vol2 = nullptr;
     ctx->dist = nullptr;
+    ctx->lut = nullptr;
     ctx->vol_bytes = 0;
     ctx->format = -1;
 }
@@ -314,6 +317,15 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         hipError_t se = hipStreamSynchronize(ctx->stream);
         drop_scratch();
         if (le != hipSuccess || se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("distance maps: ") + hipGetErrorString(le != hipSuccess ? le : se));
+    }
+    {
+        // per-axis cell-index tables of the fast path, two copies: cell units, byte offsets
+        const uint32_t padded = cell_lut_entries(nx, ny, nz);
+        HIP_TRY(ctx, hipMalloc(&ctx->lut, (size_t)padded * 2 * sizeof(uint32_t)));
+        hipLaunchKernelGGL(build_cell_luts_kernel, dim3((padded + 255) / 256), dim3(256), 0, ctx->stream, ctx->lut, nx, ny, nz, ctx->nbx, ctx->nby,
+                           (uint32_t)(cell_bytes == 8 ? 3 : 4));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     // addressing constants (vk_kernels.hpp: VolumeDesc)
     VolumeDesc &V = ctx->vdesc;
@@ -502,9 +514,11 @@ int vk_backbuffer_clear(vk_ctx *ctx) {
 }  // extern "C"
 
 template <int VOL, bool SKIP, bool SAFE>
-static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
+static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V_in, uint32_t grid, bool count) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
-    // the fast path of the cell layouts keeps its per-axis index tables in LDS (vk_kernels.hpp: fill_cell_luts)
+    VolumeDesc V = V_in;
+    if (!SKIP && V.lut) V.lut += cell_lut_entries(V.nx, V.ny, V.nz);  // byte-offset copy of the tables
+    // the fast path of the cell layouts keeps its per-axis index tables in LDS (vk_kernels.hpp: load_cell_luts)
     constexpr bool lut = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16) && !SAFE;
     const uint32_t lds = lut ? cell_lut_bytes(V.nx, V.ny, V.nz) : 0u;
     if (f16) {
@@ -725,6 +739,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     }
     VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
+    V.lut = ctx->lut;  // the no-skip variants take the byte-offset copy (set where the variant is chosen)
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
     const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);

@@ -45,6 +45,7 @@ struct VolumeDesc {
     const void *data2;    // PAIR: normals rgba16f
     const uint8_t *dist;  // PACKED: per-cell distance maps (same index as the cells), one per ray octant
     uint32_t dist_oct_stride;  // cells between consecutive octant maps; 0: one isotropic map serves all octants
+    const uint32_t *lut;       // per-axis cell-index tables of the fast path (cell units with the skip map, byte offsets without)
     uint32_t nx, ny, nz;  // voxel dims
     uint32_t nbx, nby, nbz;  // brick grid dims
     // byte offset of the cell with low-corner voxel (ix,iy,iz), b = i >> 2:
@@ -251,17 +252,34 @@ __device__ __forceinline__ bool wave_leader() {
 // neighbours (clamp), so a position one step outside the box -- the prefetch of march_stream --
 // still reads a real entry.  The three tables are stored back to back.  `shift` pre-scales the
 // entries to byte offsets when no per-cell side table is read.
-__host__ __device__ __forceinline__ uint32_t cell_lut_bytes(uint32_t nx, uint32_t ny, uint32_t nz) { return (nx + ny + nz + 9u) * 4u; }
+__host__ __device__ __forceinline__ uint32_t cell_lut_entries(uint32_t nx, uint32_t ny, uint32_t nz) { return (nx + ny + nz + 9u + 3u) & ~3u; }  // padded to whole uint4
+__host__ __device__ __forceinline__ uint32_t cell_lut_bytes(uint32_t nx, uint32_t ny, uint32_t nz) { return cell_lut_entries(nx, ny, nz) * 4u; }
 
-__device__ __forceinline__ void fill_cell_luts(const VolumeDesc &V, uint32_t *lut, uint32_t lane, uint32_t shift) {
-    const uint32_t n0 = V.nx + 3u, n1 = V.ny + 3u, n2 = V.nz + 3u, total = n0 + n1 + n2;
-    for (uint32_t e = lane; e < total; e += 64u) {
-        uint32_t j = e, n = n0, brick_mul = 64u, cell_mul = 1u;
-        if (e >= n0 + n1) { j = e - n0 - n1; n = n2; brick_mul = 64u * V.nbx * V.nby; cell_mul = 16u; }
-        else if (e >= n0) { j = e - n0; n = n1; brick_mul = 64u * V.nbx; cell_mul = 4u; }
-        const uint32_t c = min(max(j, 1u), n - 2u) - 1u;  // cell coordinate i + 1 in [0, n_vox]
-        lut[e] = (brick_mul * ((c + 3u) >> 2) + cell_mul * ((c + 3u) & 3u)) << shift;
+// Built once per volume (two copies back to back: cell units, then byte offsets) ...
+__global__ __launch_bounds__(256) void build_cell_luts_kernel(uint32_t *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx,
+                                                               uint32_t nby, uint32_t byte_shift) {
+    const uint32_t n0 = nx + 3u, n1 = ny + 3u, n2 = nz + 3u, total = n0 + n1 + n2, padded = cell_lut_entries(nx, ny, nz);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < padded; e += gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        if (e < total) {
+            uint32_t j = e, n = n0, brick_mul = 64u, cell_mul = 1u;
+            if (e >= n0 + n1) { j = e - n0 - n1; n = n2; brick_mul = 64u * nbx * nby; cell_mul = 16u; }
+            else if (e >= n0) { j = e - n0; n = n1; brick_mul = 64u * nbx; cell_mul = 4u; }
+            const uint32_t c = min(max(j, 1u), n - 2u) - 1u;  // cell coordinate i + 1 in [0, n_vox]
+            v = brick_mul * ((c + 3u) >> 2) + cell_mul * ((c + 3u) & 3u);
+        }
+        out[e] = v;
+        out[padded + e] = v << byte_shift;
     }
+}
+
+// ... and copied into LDS by every wave of the march: a handful of 16-byte loads instead of ~200 VALU
+// instructions of index arithmetic per wave.
+__device__ __forceinline__ void load_cell_luts(const VolumeDesc &V, uint32_t *lut, uint32_t lane) {
+    const uint32_t n4 = cell_lut_entries(V.nx, V.ny, V.nz) >> 2;
+    const uint4 *src = reinterpret_cast<const uint4 *>(V.lut);
+    uint4 *dst = reinterpret_cast<uint4 *>(lut);
+    for (uint32_t e = lane; e < n4; e += 64u) dst[e] = src[e];
 }
 
 // Bounds-checked view of the cell array for the fast path (< 4 GiB): a raw buffer resource, so an
@@ -333,7 +351,7 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 //
 // SAFE=false (the fast path of the PACKED layouts) looks the cell index up instead of computing it:
 // idx = Tx[ix] + Ty[iy] + Tz[iz] with three small per-axis tables in LDS (`lut`, filled by the kernel:
-// see fill_cell_luts).  Three ds_read_b32 (not VALU) + one v_add3 replace the 14 integer VALU
+// see load_cell_luts).  Three ds_read_b32 (not VALU) + one v_add3 replace the 14 integer VALU
 // instructions of the closed form -- the loop is VALU-issue bound.  Every table entry is a valid
 // non-negative partial index and LDS reads outside the allocation return 0, so any combination stays
 // inside the cell array: no clamp.
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     constexpr bool USE_LUT = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16) && !SAFE;
     extern __shared__ uint32_t cell_lut[];
     if (USE_LUT) {  // all 64 lanes are still here
-        fill_cell_luts(V, cell_lut, lane, SKIP ? 0u : V.sh_x);
+        load_cell_luts(V, cell_lut, lane);
         __syncthreads();
     }
     if (!pm.valid) return;
