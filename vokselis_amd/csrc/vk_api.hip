@@ -636,6 +636,10 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
         if (active[a] != active[b]) return active[a] > active[b];
         return cost[a] > cost[b];
     });
+    // Position q goes to XCD q % 8 (rank q % N first, when the frame is partitioned): dealt straight, bin 0
+    // would receive the heaviest tile of every round of 8.  Reverse every other round (snake) so the bins'
+    // sums even out; the active tiles stay in front.
+    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(ctx->order.begin() + g, ctx->order.begin() + g + 8);
     ctx->order_active = n_active;
     ctx->order_pos.resize(n);
     for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
