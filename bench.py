@@ -264,6 +264,25 @@ def main():
                     gb = (ss * B_STEP + W * H * B_RAY) / (ms * 1e-3) / 1e9
                     extras[f"{name}_{mode}"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+            # the compute twin (raycast_compute.wgsl `single`) on the xor example's own configuration:
+            # 256^3 rgba16f pair generated on the device, 1280x720, xor camera, dt = 0.01; 16 B per step
+            try:
+                cx = V.Context(1280, 720, V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), 1280 / 720), device=local_rank,
+                               backbuffer=(1280, 720), out_format=V.OUT_RGBA16F)
+                try:
+                    V.VolumeTexture.generate_xor(cx, (256,) * 3, 0.0)
+                    cx.update()
+                    cx.reset_step_counts()
+                    V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, flags=V.RENDER_COUNT).record(cx)
+                    sr, ss = cx.step_counts()
+                    ms = time_launches(cx, V.RaycastPipeline(V.MODE_COMPUTE_NEAREST), it)
+                    gb = (ss * 16 + 1280 * 720 * B_RAY) / (ms * 1e-3) / 1e9
+                    extras["xor_compute_nearest_720p"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
+                                                          "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+                finally:
+                    cx.close()
+            except Exception as e:  # a side measurement must not take the headline down
+                extras["xor_compute_nearest_720p"] = {"error": str(e)}
             out["extras"] = extras
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

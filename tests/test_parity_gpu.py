@@ -264,8 +264,21 @@ def test_compute_nearest_mode(V, O, golden, cameras):
     """raycast_compute.wgsl `single` and `tile` (A10-A12) against the golden vectors."""
     g = golden["compute_128x72"]
     den, nrm = g["density"].view(np.float16), g["normals"].view(np.float16)
-    img, steps, _ = gpu_render(V, cameras["xor_16x9"], den, 128, 72, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST)
-    assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
+    # AUTO / PACKED: bricked 16-byte (density, normals) records, pipelined kernel; LINEAR: the two dense volumes
+    first = None
+    for lay in (V.LAYOUT_AUTO, V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
+        img, steps, _ = gpu_render(V, cameras["xor_16x9"], den, 128, 72, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay)
+        assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all(), lay
+        first = img if first is None else first
+        assert (img.view(np.uint32) == first.view(np.uint32)).all(), "the record layout changes no bit"
+    # non-multiple-of-4 dims, a tile that hangs off the image, and long steps (speculative request far outside)
+    rng = np.random.default_rng(3)
+    d2 = rng.random((19, 10, 33, 4), np.float32).astype(np.float16); n2 = (rng.random((19, 10, 33, 4), np.float32) * 2 - 1).astype(np.float16)
+    for dt in (1.0, 7.5):
+        ref, rsteps, _ = O.render(cameras["xor_16x9"], d2, 96, 54, mode=O.MODE_COMPUTE_NEAREST, volume2=n2, dt_scale=dt)
+        for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
+            img, steps, _ = gpu_render(V, cameras["xor_16x9"], d2, 96, 54, vol2=n2, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt)
+            assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dt, lay)
     # the reference's tile loop: (H/256+1) x (W/256+1) offsets, here with 64-px tiles incl. off-screen ones
     ctx = V.Context(128, 72, backbuffer=(128, 72), out_format=V.OUT_RGBA32F)
     try:

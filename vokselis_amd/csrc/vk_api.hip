@@ -199,13 +199,21 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         // beyond ~4 GiB of cells the march stops being cache-resident and the 8-16x inflation of the cell
         // layouts turns into HBM traffic: 9^3 dense bricks (1.42x) win there (1024^3 f16: 8.5 -> 5.0 ms)
         const double cell_bytes = cells * (format == VK_FMT_R8_UNORM ? 16.0 : 16.0);
-        if (format == VK_FMT_RGBA16F_PAIR) layout = VK_LAYOUT_LINEAR;
+        if (format == VK_FMT_RGBA16F_PAIR) {
+            // 16-byte (density, normals) records in 4^3 bricks while the array and its index tables stay small
+            const double rec_bytes = ((double)((nx + 3) / 4)) * ((ny + 3) / 4) * ((nz + 3) / 4) * 64.0 * 16.0;
+            layout = (rec_bytes <= (double)kPairOob && pair_lut_entries(nx, ny, nz) * 4u <= 16384u) ? VK_LAYOUT_PACKED : VK_LAYOUT_LINEAR;
+        }
         else if (cell_bytes > 4.0 * 1024 * 1024 * 1024) layout = VK_LAYOUT_BRICKED;
         else layout = format == VK_FMT_R8_UNORM ? VK_LAYOUT_PACKED_PAIRS : VK_LAYOUT_PACKED;
     }
-    if (format == VK_FMT_RGBA16F_PAIR && layout != VK_LAYOUT_LINEAR)
-        return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR volumes use the linear layout (nearest-neighbour loads)");
-    if (format == VK_FMT_RGBA16F_PAIR && layout == VK_LAYOUT_BRICKED) return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR volumes use the linear layout");
+    if (format == VK_FMT_RGBA16F_PAIR && layout != VK_LAYOUT_LINEAR && layout != VK_LAYOUT_PACKED)
+        return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR volumes use VK_LAYOUT_LINEAR or VK_LAYOUT_PACKED (bricked 16-byte records)");
+    if (format == VK_FMT_RGBA16F_PAIR && layout == VK_LAYOUT_PACKED) {
+        const double rec_bytes = ((double)((nx + 3) / 4)) * ((ny + 3) / 4) * ((nz + 3) / 4) * 64.0 * 16.0;
+        if (rec_bytes > (double)kPairOob || pair_lut_entries(nx, ny, nz) * 4u > 16384u)
+            return fail(ctx, VK_ERR_UNSUPPORTED, "RGBA16F_PAIR record layout holds <= 1.25 GiB of records: use VK_LAYOUT_LINEAR");
+    }
     free_volume(ctx);
     ctx->empty_fraction = 0.0;
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
@@ -227,6 +235,26 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         ctx->vol_bytes = n_vox * bpv * (d_src2 ? 2 : 1);
         ctx->vol_kind = format == VK_FMT_R16_FLOAT ? VOL_LINEAR_F16 : VOL_LINEAR_U8;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return VK_OK;
+    }
+    if (format == VK_FMT_RGBA16F_PAIR) {  // layout == VK_LAYOUT_PACKED: interleaved records, 4^3 bricks
+        ctx->nbx = (nx + 3) / 4; ctx->nby = (ny + 3) / 4; ctx->nbz = (nz + 3) / 4;
+        const uint64_t n_rec = (uint64_t)ctx->nbx * ctx->nby * ctx->nbz * 64u;
+        auto drop_src = [&]() { if (own_src) { (void)hipFree(const_cast<void *>(d_src)); (void)hipFree(const_cast<void *>(d_src2)); } };
+        if (hipMalloc(&ctx->vol, n_rec * 16) != hipSuccess) { drop_src(); return fail(ctx, VK_ERR_OOM, "record array allocation failed"); }
+        const uint32_t padded = pair_lut_entries(nx, ny, nz);
+        if (hipMalloc(&ctx->lut, (size_t)padded * sizeof(uint32_t)) != hipSuccess) { drop_src(); return fail(ctx, VK_ERR_OOM, "index table allocation failed"); }
+        ctx->vol_bytes = n_rec * 16;
+        ctx->vol_kind = VOL_PAIRB;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_rec + 255) / 256, 1ull << 22);
+        hipLaunchKernelGGL(pack_pairs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint2 *)d_src, (const uint2 *)d_src2, (uint4 *)ctx->vol, nx, ny, nz,
+                           ctx->nbx, ctx->nby, n_rec);
+        hipLaunchKernelGGL(build_pair_luts_kernel, dim3((padded + 255) / 256), dim3(256), 0, ctx->stream, ctx->lut, nx, ny, nz, ctx->nbx, ctx->nby);
+        hipError_t le = hipGetLastError();
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        drop_src();
+        if (le != hipSuccess || se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("record re-layout: ") + hipGetErrorString(le != hipSuccess ? le : se));
+        ctx->vdesc.max_off = (int64_t)(n_rec - 1) * 16;
         return VK_OK;
     }
     if (layout == VK_LAYOUT_BRICKED) {
@@ -429,7 +457,7 @@ int vk_volume_generate_xor(vk_ctx *ctx, uint32_t nx, uint32_t ny, uint32_t nz, f
     hipLaunchKernelGGL(xor_generate_kernel, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, ctx->stream, (uint2 *)d, (uint2 *)d2, nx, ny, nz, time);
     e = hipGetLastError();
     if (e != hipSuccess) { (void)hipFree(d); (void)hipFree(d2); return fail(ctx, VK_ERR_HIP, std::string("xor generator launch: ") + hipGetErrorString(e)); }
-    return build_from_dense(ctx, d, d2, true, nx, ny, nz, VK_FMT_RGBA16F_PAIR, VK_LAYOUT_LINEAR);
+    return build_from_dense(ctx, d, d2, true, nx, ny, nz, VK_FMT_RGBA16F_PAIR, VK_LAYOUT_AUTO);
 }
 
 int vk_volume_empty_fraction(vk_ctx *ctx, double *fraction) {
@@ -747,7 +775,17 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
     const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
-    if (mode == VK_MODE_COMPUTE_NEAREST) {
+    if (mode == VK_MODE_COMPUTE_NEAREST && ctx->vol_kind == VOL_PAIRB) {
+        const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+        const uint32_t lds = pair_lut_entries(V.nx, V.ny, V.nz) * 4u;
+        if (f16) {
+            if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, true>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+            else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, false>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        } else {
+            if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, true>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+            else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, false>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        }
+    } else if (mode == VK_MODE_COMPUTE_NEAREST) {
         const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
         if (f16) {
             if (count) hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, V);

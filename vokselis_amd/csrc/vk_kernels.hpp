@@ -37,7 +37,9 @@ constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
 // voxels, clamp-to-edge baked in): brick b holds voxels [8b-1, 8b+7] per axis, so the 8 taps of any
 // sample come from ONE brick at fixed local offsets (+1, +9, +81).  1.42x the dense bytes instead
 // of 8-16x: the layout for volumes far larger than the caches.
-enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6 };
+// PAIRB: the two rgba16f volumes of the compute mode interleaved as 16-byte (density, normals) records in
+// 4^3 bricks: one nearest-neighbour step is ONE aligned 16-byte load.
+enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6, VOL_PAIRB = 7 };
 enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 
 struct VolumeDesc {
@@ -681,6 +683,152 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
     float s = (x - e0) * inv;
     s = fminf(fmaxf(s, 0.0f), 1.0f);
     return (s * s) * fmaf(-2.0f, s, 3.0f);
+}
+
+// ---- COMPUTE_NEAREST on the bricked record layout ---------------------------------------------
+// Per-axis tables as for the cells, here for voxel i in [-kPairPad, n - 1 + kPairPad]: in-range entries
+// are byte offsets of the record, out-of-range ones the marker kPairOob.  The records are read through
+// a raw buffer resource sized to the array, so any sum that contains a marker is past the end and
+// the load returns zeros -- exactly the zeros this build defines for out-of-range texel loads (A.2).
+constexpr uint32_t kPairPad = 8;
+constexpr uint32_t kPairOob = 0x50000000u;  // > any record offset (array <= kPairOob bytes); 3 markers do not wrap
+__host__ __device__ __forceinline__ uint32_t pair_lut_entries(uint32_t nx, uint32_t ny, uint32_t nz) { return (nx + ny + nz + 6u * kPairPad + 3u) & ~3u; }
+
+__global__ __launch_bounds__(256) void build_pair_luts_kernel(uint32_t *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby) {
+    const uint32_t n0 = nx + 2u * kPairPad, n1 = ny + 2u * kPairPad, n2 = nz + 2u * kPairPad, total = n0 + n1 + n2, padded = pair_lut_entries(nx, ny, nz);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < padded; e += gridDim.x * blockDim.x) {
+        uint32_t v = kPairOob;
+        if (e < total) {
+            uint32_t j = e, n = nx, brick_mul = 64u, cell_mul = 1u;
+            if (e >= n0 + n1) { j = e - n0 - n1; n = nz; brick_mul = 64u * nbx * nby; cell_mul = 16u; }
+            else if (e >= n0) { j = e - n0; n = ny; brick_mul = 64u * nbx; cell_mul = 4u; }
+            if (j >= kPairPad && j < n + kPairPad) { const uint32_t i = j - kPairPad; v = (brick_mul * (i >> 2) + cell_mul * (i & 3u)) << 4; }
+        }
+        out[e] = v;
+    }
+}
+
+// dense x-fastest (density, normals) -> bricked 16-byte records
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2 *__restrict__ den, const uint2 *__restrict__ nrm, uint4 *__restrict__ dst,
+                                                         uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_rec) {
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_rec; id += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t brick = id >> 6;
+        const uint32_t w = (uint32_t)(id & 63u);
+        const uint32_t bx = (uint32_t)(brick % nbx);
+        const uint64_t rest = brick / nbx;
+        const uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        const uint32_t x = bx * 4 + (w & 3u), y = by * 4 + ((w >> 2) & 3u), z = bz * 4 + (w >> 4);
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (x < nx && y < ny && z < nz) {
+            const size_t src = (size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)z);
+            const uint2 d = den[src], n = nrm[src];
+            r = make_uint4(d.x, d.y, n.x, n.y);
+        }
+        dst[id] = r;
+    }
+}
+
+// Same arithmetic as raymarch_compute_kernel below (raycast_compute.wgsl:62-131), one 16-byte record
+// per step, software-pipelined: p = eye + t*dir does not depend on the loads, so the next step's
+// record is requested before this step is shaded.  A lone wave of this mode used to pay a full
+// cache-miss latency per step (<= 346 dependent steps per ray).
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const LaunchDesc L, const VolumeDesc V) {
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;
+    const uint32_t lane = threadIdx.x;
+    const PixelMap pm = map_pixel(L, lb, lane);
+    extern __shared__ uint32_t pair_lut[];
+    {
+        const uint32_t n4 = pair_lut_entries(V.nx, V.ny, V.nz) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(V.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(pair_lut);
+        for (uint32_t e = lane; e < n4; e += 64u) dst[e] = src[e];
+        __syncthreads();
+    }
+    if (!pm.valid) return;
+
+    float dimx = (float)L.W, dimy = (float)L.H;
+    float aspect_ratio = dimy / dimx;
+    float scx = 2.0f * (float)pm.x / dimx - 1.0f;
+    float scy = 2.0f * (float)pm.y / dimy - 1.0f;
+    scy = scy * -aspect_ratio;
+    float vp[4], vt[4];
+    mat4_mul_vec4(L.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(L.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
+    float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
+    normalize3(dir[0], dir[1], dir[2]);
+
+    const float clr[3] = {0.023f, 0.02f, 0.02f};  // :118, clear alpha 0
+    float C[3] = {clr[0], clr[1], clr[2]};
+    uint32_t n_iter = 0;
+    float t0, t1;
+    intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
+    if (t0 < t1) {  // :123
+        t0 = fmaxf(t0, 0.0f);
+        float A = 0.1f;  // get_col2 :63
+        const float bsx = (float)V.nx, bsy = (float)V.ny, bsz = (float)V.nz;
+        float dtx = 1.0f / (bsx * fabsf(dir[0]));
+        float dty = 1.0f / (bsy * fabsf(dir[1]));
+        float dtz = 1.0f / (bsz * fabsf(dir[2]));
+        const float dt = L.dt_scale * fmaxf(fminf(dtx, fminf(dty, dtz)), 0.01f);  // :66-68
+        const float hbx = bsx / 2.0f, hby = bsy / 2.0f, hbz = bsz / 2.0f;
+        float l1x = -2.0f, l1y = -2.0f, l1z = -1.0f, l2x = 1.0f, l2y = 1.0f, l2z = -1.0f;
+        normalize3(l1x, l1y, l1z);
+        normalize3(l2x, l2y, l2z);
+        const uint32_t *luty = pair_lut + (V.nx + 2u * kPairPad), *lutz = pair_lut + (V.nx + V.ny + 4u * kPairPad);
+        const __amdgpu_buffer_rsrc_t recs = cell_buffer(V.data, (uint32_t)V.max_off + 16u);
+        struct Req { float px, py, pz; u32x4_t r; };
+        auto request = [&](float t) -> Req {
+            Req q;
+            q.px = eye[0] + t * dir[0]; q.py = eye[1] + t * dir[1]; q.pz = eye[2] + t * dir[2];
+            // ivec3 truncation (:75); |p| stays within a few steps of the box, so the conversions are in range
+            const int ix = (int)((q.px + 1.0f) * hbx), iy = (int)((q.py + 1.0f) * hby), iz = (int)((q.pz + 1.0f) * hbz);
+            const uint32_t off = pair_lut[ix + (int)kPairPad] + luty[iy + (int)kPairPad] + lutz[iz + (int)kPairPad];
+            q.r = __builtin_amdgcn_raw_buffer_load_b128(recs, (int)off, 0, 0);
+            return q;
+        };
+        float t = t0;
+        Req cur = request(t), nxt = cur;
+        for (;;) {  // :69, entered with t < t1
+            const float tn = t + dt;
+            nxt = request(tn);
+            const float px = cur.px, py = cur.py, pz = cur.pz;
+            const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
+            float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
+            float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
+            n_iter++;
+            float sh = fmaxf(0.0f, (0.0f * n0 + -1.0f * n1) + 0.0f * n2);
+            float va = (vc3 * vc3) * vc3;
+            va = smoothstepf(0.0f, 0.7f, va);
+            float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
+            float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
+            float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
+            float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
+            float sh0 = sh * (1.0f - 0.2f) + (bl * 0.0f) * 0.2f;
+            float sh1 = sh0;
+            float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
+            float w = (1.0f - A) * va;
+            C[0] = (C[0] + w * col0 * sh0) + clr[0] * 0.0f * (1.0f - va);
+            C[1] = (C[1] + w * col1 * sh1) + clr[1] * 0.0f * (1.0f - va);
+            C[2] = (C[2] + w * col2 * sh2) + clr[2] * 0.0f * (1.0f - va);
+            A = A + w * (1.0f - 0.0f);
+            if (A >= 0.95f) break;
+            t = tn;
+            if (!(t < t1)) break;
+            cur = nxt;
+        }
+        asm volatile("" ::"v"(nxt.r));  // the last request is consumed on the exit path too (keeps it ahead of the shading)
+    }
+    store_pixel<OUT>(L.out, pm.out_index, C[0], C[1], C[2], 1.0f);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+        }
+    }
 }
 
 template <int OUT, bool COUNT>
