@@ -49,7 +49,7 @@ enum vk_out_format { VK_OUT_RGBA32F = 0, VK_OUT_RGBA16F = 1 };
 enum vk_layout {
     VK_LAYOUT_AUTO = 0,
     VK_LAYOUT_LINEAR = 1, /* x-fastest as uploaded; 8 scalar taps per sample (validation kernel) */
-    VK_LAYOUT_PACKED = 2, /* 4^3-bricked cells, each holding its 8 trilinear taps (+ skip map) */
+    VK_LAYOUT_PACKED = 2, /* 4^3-bricked cells, each holding its 8 trilinear taps (+ per-octant skip maps) */
     VK_LAYOUT_PACKED_PAIRS = 3, /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
     VK_LAYOUT_BRICKED = 4 /* dense 8^3 bricks + 1-voxel apron (9^3): 1.42x the dense bytes, 8 taps from one
                              brick; for volumes far larger than the caches (no skip map) */
@@ -79,7 +79,9 @@ int vk_abi_version(void);
 /* ---- inputs ------------------------------------------------------------------------------ */
 /* VolumeTexture::new: create_texture + queue.write_texture, src/context/volume_texture.rs:32-59.
  * `host` is the dense x-fastest array (index x + nx*(y + ny*z)); `host2` only for RGBA16F_PAIR
- * (normals).  The library re-lays it out on the device (layout) and builds the skip map. */
+ * (normals).  The library re-lays it out on the device (layout) and builds the skip maps.
+ * RGBA16F_PAIR accepts VK_LAYOUT_LINEAR (two dense arrays) or VK_LAYOUT_PACKED (16-byte density+normals
+ * records in 4^3 bricks, <= 1.25 GiB; the AUTO choice up to that size). */
 int vk_volume_upload(vk_ctx *ctx, const void *host, const void *host2, uint32_t nx, uint32_t ny, uint32_t nz,
                      int format, int layout);
 /* Same, but the dense source already lives in device memory of this GPU (large synthetic volumes). */
