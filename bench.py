@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather path even at N = 1 (self-test)")
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="N > 1: frames marched concurrently per rank (own stream each)")
+    ap.add_argument("--gather-batch", type=int, default=8, help="N > 1: frames moved per gather call (a collective call costs ~100 us of host time)")
     return ap.parse_args()
 
 
@@ -174,7 +176,7 @@ def main():
             def drain():
                 pass
         else:
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=TILE, root=0)
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=TILE, root=0, batch=args.gather_batch, frames_in_flight=args.frames_in_flight)
             step, drain = tpr.submit, tpr.flush
 
         for k in range(args.warmup):
@@ -223,7 +225,7 @@ def main():
                                 "bonsai camera (1,.5,1,(.5,.5,.5)), NAIVE_TRILINEAR, dt_scale 0.5 (<=513 steps/ray), rgba16f out",
                     "layout": {"pairs": "4^3-bricked cells, 4 (tap,delta) f16 pairs / 16 B", "packed": "4^3-bricked cells, 8 u8 taps / 8 B", "bricked": "dense 9^3 bricks, 8 scalar taps"}[args.layout],
                     "skip": not args.no_skip,
-                    "partition": "single launch" if world == 1 else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0",
+                    "partition": "single launch" if world == 1 else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0, {args.gather_batch} frames per gather call, {args.frames_in_flight} frames in flight per rank",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
                 },
                 "roofline": {

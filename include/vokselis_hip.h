@@ -133,6 +133,12 @@ int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t ti
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots);
 int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                         float dt_scale, uint32_t flags, void *compact_out);
+/* The same launch placed on a caller-owned HIP stream without synchronising anything: several frames can be
+ * in flight on different streams (each into its own compact buffer), which is what lets a rank holding 1/N of
+ * a small frame keep its GPU busy.  The caller orders that stream against the consumer of `compact_out`.
+ * VK_RENDER_COUNT is refused (the counters live on the context's own stream). */
+int vk_render_partition_on(vk_ctx *ctx, void *hip_stream, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                           float dt_scale, uint32_t flags, void *compact_out);
 /* The partition deals tiles heaviest-first (a launch/balance heuristic derived from the camera):
  * position q of the order belongs to rank q % nranks, slot q / nranks.  order_out[q] = row-major
  * tile id; identical on every rank for identical camera, volume dims and backbuffer size. */

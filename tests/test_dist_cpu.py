@@ -28,22 +28,29 @@ def _worker(rank, world, port, W, H, ts, q):
     try:
         vol = O.volume_standin_u8(32)
         cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-        fg = D.FrameGather(W, H, ts, torch.float32, torch.device("cpu"), root=0)
+        # two frames per collective call, two batches in flight through the two buffer sets
+        B = 2
+        dts = (1.0, 0.5, 0.75)  # 3 frames: one full batch + one partial (flushed with count = 1)
+        fg = D.FrameGather(W, H, ts, torch.float32, torch.device("cpu"), root=0, batch=B)
         tx, _ = D.tiles_xy(W, H, ts)
+        compact, gathered = fg.buffers()
         works = []
-        for k, dt in enumerate((1.0, 0.5)):  # two frames in flight through the two buffers
-            buf = fg.compact[k % 2].numpy()
+        for k, dt in enumerate(dts):
+            g, b = divmod(k, B)
+            buf = compact[g % 2][b].numpy()
             for j, t in enumerate(D.local_tiles(W, H, ts, rank, world)):
                 x0, y0 = (t % tx) * ts, (t // tx) * ts
                 full, _, _ = O.render(cam, vol, W, H, dt_scale=dt, tile=(x0, y0, ts, ts), want_counts=False)
                 tile = full[y0:y0 + ts, x0:x0 + ts]
                 buf[j, :tile.shape[0], :tile.shape[1]] = tile
-            works.append(fg.start(k, fg.slots if k == 0 else None))
+            if b == B - 1 or k == len(dts) - 1:
+                works.append(fg.start(g % 2, None, b + 1))
         for w in works:
             w.wait()
         if rank == 0:
-            for k, dt in enumerate((1.0, 0.5)):
-                frame = D.untile_reference(fg.gathered[k % 2].numpy(), W, H, ts)
+            for k, dt in enumerate(dts):
+                g, b = divmod(k, B)
+                frame = D.untile_reference(gathered[g % 2][:, b].numpy(), W, H, ts)
                 ref, _, _ = O.render(cam, vol, W, H, dt_scale=dt, want_counts=False)
                 q.put((k, float(np.abs(frame - ref).max()), bool((frame == ref).all())))
     finally:
@@ -61,6 +68,6 @@ def test_gloo_world2_tile_gather(W, H, ts):
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    got = sorted(q.get(timeout=5) for _ in range(2))
-    assert [g[0] for g in got] == [0, 1]
+    got = sorted(q.get(timeout=5) for _ in range(3))
+    assert [g[0] for g in got] == [0, 1, 2]
     assert all(g[2] for g in got), got  # bit-identical to the single-process oracle frame

@@ -191,6 +191,61 @@ def test_partition_untile_equals_frame(V, O):
             ctx.close()
 
 
+def test_tile_parallel_renderer_over_rccl_world1(V, O):
+    """The production N > 1 driver (TileParallelRenderer: partition march, batched RCCL gather, un-tile) run
+    as a world of one over RCCL: every delivered frame equals the single-launch frame bit for bit, across
+    full batches, a partial batch closed by flush(), and a camera change in the middle of a batch."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from vokselis_amd.dist import TileParallelRenderer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    W, H = 320, 200
+    vol = O.volume_standin_u8(64)
+    cam_a = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+    ctx = V.Context(W, H, cam_a, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    ref_ctx = V.Context(W, H, cam_a, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    try:
+        for c in (ctx, ref_ctx):
+            V.VolumeTexture(c, vol); c.update()
+
+        def direct(dt):
+            V.RaycastPipeline(dt_scale=dt).record(ref_ctx)
+            return ref_ctx.read_backbuffer().view(np.uint16).copy()
+
+        for fif in (1, 2):  # frames in flight per rank: serial, and two streams
+          with torch.cuda.stream(torch.cuda.Stream()):  # the collective is ordered against torch's current stream
+            for c in (ctx, ref_ctx):
+                c.camera.set_zoom(1.0); c.update()
+            pipe = V.RaycastPipeline(dt_scale=1.0)
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=3, frames_in_flight=fif)
+            for k, dt in enumerate((1.0, 0.5, 0.25, 0.75)):   # one full batch + one frame
+                pipe.dt_scale = dt
+                tpr.submit(k)
+            tpr.flush()
+            assert (ctx.read_backbuffer().view(np.uint16) == direct(0.75)).all()
+            pipe.dt_scale = 0.5
+            tpr.submit(4); tpr.submit(5)                      # partial batch
+            # camera change inside a batch: the active tile set changes size
+            for c in (ctx, ref_ctx):
+                c.camera.set_zoom(2.5)
+                c.update()
+            tpr.submit(6)
+            tpr.flush()
+            assert (ctx.read_backbuffer().view(np.uint16) == direct(0.5)).all()
+    finally:
+        ctx.close(); ref_ctx.close()
+        if created:
+            dist.destroy_process_group()
+
+
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)

@@ -14,10 +14,11 @@ with torch.cuda.stream(stream):
         ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F, stream=stream.cuda_stream)
         V.VolumeTexture.generate_standin(ctx, (256,) * 3); ctx.update()
         pipe = V.RaycastPipeline(dt_scale=0.5)
-        tpr = TileParallelRenderer(ctx, pipe, tile_size=64)
+        B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+        tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=B)
         for k in range(50): tpr.submit(k)
         tpr.flush(); torch.cuda.synchronize()
-        K = 2000
+        K = 300
         t0 = time.perf_counter()
         for k in range(K): tpr.submit(k)
         t_cpu = time.perf_counter() - t0

@@ -57,3 +57,8 @@ xk = xcc; wx = np.bincount(xk, weights=est); print("per-XCD estimated work:", (w
 percu = np.bincount((key // 4).astype(np.int64) - (key // 4).min(), weights=dur); percu = percu[percu > 0]
 print("per-CU summed wave time: mean %.0f max %.0f min %.0f" % (percu.mean(), percu.max(), percu.min()))
 ctx.close()
+# heaviest blocks by estimated issue slots: where are they and what do they execute?
+top = np.argsort(-est)[:8]
+lbs = np.nonzero(ok)[0]
+for i in top:
+    print(f"block lb={lbs[i]} est {est[i]:.0f}: loop trips {wo[i]:.0f}, walk trips {wi[i]:.0f}, sample execs {ws[i]:.0f}, duration(instrumented) {dur[i]:.0f} us")

@@ -105,11 +105,14 @@ class Context:
         if rc != N.VK_OK:
             msg = L.vk_last_error(None)
             raise N.VokselisError(rc, msg.decode() if msg else "")
+        self.stream_handle = None
         if stream is not None:
             N.check(self._h, L.vk_ctx_set_stream(self._h, C.c_void_p(stream)))
+            self.stream_handle = stream
         self.width, self.height = width, height
         # Context::new: Camera::new(1., 0.5, 1., (0.,0.,0.), w/h) when none is given (src/context.rs:124-132)
         self.camera = camera if camera is not None else Camera(1.0, 0.5, 1.0, (0.0, 0.0, 0.0), width / height)
+        self.camera_epoch = 0  # bumped whenever a camera blob is uploaded (per-camera caches key on it)
         self.global_uniform = Uniform()
         bw, bh = backbuffer if backbuffer is not None else HdrBackBuffer.DEFAULT_RESOLUTION
         self.render_backbuffer = HdrBackBuffer(bw, bh, out_format)
@@ -156,6 +159,7 @@ class Context:
             N.check(self._h, N.lib().vk_set_camera(self._h, self.camera.get_proj_view_matrix()))
             self.camera.updated = False
             self._first_frame = False
+            self.camera_epoch += 1
 
     def resize(self, width: int, height: int):
         """Context::resize, src/context.rs:238-249: the *window* size drives the camera aspect; the
@@ -168,9 +172,15 @@ class Context:
         N.check(self._h, N.lib().vk_backbuffer_resize(self._h, width, height, fmt))
         self.render_backbuffer = HdrBackBuffer(width, height, fmt)
 
+    def set_stream(self, hip_stream: int | None):
+        """Run this context's work on a caller-owned HIP stream (None: the context's own)."""
+        N.check(self._h, N.lib().vk_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+        self.stream_handle = hip_stream
+
     def set_camera_blob(self, blob: bytes):
         N.check(self._h, N.lib().vk_set_camera(self._h, blob))
         self._first_frame = False
+        self.camera_epoch += 1
 
     def sync(self):
         N.check(self._h, N.lib().vk_ctx_sync(self._h))
@@ -320,9 +330,15 @@ class RaycastPipeline:
         tx, ty, tw, th = (0, 0, bb.width, bb.height) if tile is None else tile
         N.check(ctx.handle, N.lib().vk_render(ctx.handle, self.mode, tx, ty, tw, th, self.dt_scale, self.flags))
 
-    def record_partition(self, ctx: Context, tile_size: int, rank: int, nranks: int, compact_ptr: int):
-        N.check(ctx.handle, N.lib().vk_render_partition(ctx.handle, self.mode, tile_size, rank, nranks, self.dt_scale,
-                                                       self.flags, C.c_void_p(compact_ptr)))
+    def record_partition(self, ctx: Context, tile_size: int, rank: int, nranks: int, compact_ptr: int, stream: int | None = None):
+        """March this rank's tiles into a compact buffer; `stream` places the launch on a caller-owned HIP
+        stream without synchronising (frames in flight), default: the context's stream."""
+        if stream:
+            N.check(ctx.handle, N.lib().vk_render_partition_on(ctx.handle, C.c_void_p(stream), self.mode, tile_size, rank, nranks,
+                                                              self.dt_scale, self.flags, C.c_void_p(compact_ptr)))
+        else:
+            N.check(ctx.handle, N.lib().vk_render_partition(ctx.handle, self.mode, tile_size, rank, nranks, self.dt_scale,
+                                                           self.flags, C.c_void_p(compact_ptr)))
 
 
 def partition_slots(width: int, height: int, tile_size: int, nranks: int) -> int:

@@ -672,8 +672,9 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     ctx->order_pos.resize(n);
     for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
     if (ctx->d_order_cap < n) {
-        if (ctx->trace) (void)hipFree(ctx->trace);
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
+        // other streams' launches (frames in flight) may still read the old tables
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (ctx->d_order) (void)hipFree(ctx->d_order);
         if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
         ctx->d_order = ctx->d_order_pos = nullptr;
         ctx->d_order_cap = 0;
@@ -681,7 +682,10 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
         HIP_TRY(ctx, hipMalloc(&ctx->d_order_pos, n * sizeof(uint32_t)));
         ctx->d_order_cap = n;
     }
-    // earlier launches may still read the old table: these copies are stream-ordered behind them
+    // Earlier launches may still read the old table.  On this context's stream the copies are ordered behind
+    // them; launches placed on other streams (vk_render_partition_on: frames in flight) are not, so a change
+    // of the order (new camera / region) first waits for the device -- once per camera, not per frame.
+    if (!ctx->order_key.empty()) HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors may be rewritten by the next call
@@ -843,6 +847,20 @@ int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank
     if (!ctx) return VK_ERR_INVALID;
     if (!compact_out) return fail(ctx, VK_ERR_INVALID, "vk_render_partition: compact_out is NULL");
     return render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
+}
+
+int vk_render_partition_on(vk_ctx *ctx, void *hip_stream, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                           float dt_scale, uint32_t flags, void *compact_out) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!compact_out || !hip_stream) return fail(ctx, VK_ERR_INVALID, "vk_render_partition_on: NULL argument");
+    if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_partition_on: counters belong to the context's own stream");
+    // Frames in flight: the launch goes to the caller's stream, nothing is synchronised.  The caller orders
+    // that stream against whatever consumes / recycles `compact_out`.
+    hipStream_t saved = ctx->stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    const int rc = render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
+    ctx->stream = saved;
+    return rc;
 }
 
 int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nranks, uint32_t *n_active_tiles, uint32_t *n_active_slots) {

@@ -588,6 +588,83 @@ __device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, C
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
+// The dense 9^3-brick layouts, software-pipelined the same way: these serve volumes far larger than
+// the caches, where every step's four x-pair loads are HBM/fabric latency.  The next trip's loads are
+// requested (clamped indices, so always inside the array) before this trip's sample is evaluated.
+template <int VOL, bool COUNT>
+__device__ __forceinline__ void march_b9_stream(const VolumeDesc &V, RayState &r, Census &cs) {
+    static_assert(VOL == VOL_B9U8 || VOL == VOL_B9F16, "9^3 brick layouts");
+    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+    const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
+    if (!(t < t1 && A < 0.95f)) return;
+    typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+    typedef uint32_t u32_unaligned __attribute__((aligned(2)));
+    struct Taps { uint32_t p00, p10, p01, p11; };  // x pairs at (y, z) = (0,0) (1,0) (0,1) (1,1)
+    auto request = [&](float ux, float uy, float uz) -> Taps {
+        const int cx = med3_i32(cvt_floor_i32(ux), -1, mx) + 1, cy = med3_i32(cvt_floor_i32(uy), -1, my) + 1, cz = med3_i32(cvt_floor_i32(uz), -1, mz) + 1;
+        const uint32_t brick = (uint32_t)(((cz >> 3) * (int)V.nby + (cy >> 3)) * (int)V.nbx + (cx >> 3));
+        const uint32_t local = (uint32_t)((cz & 7) * 81 + (cy & 7) * 9 + (cx & 7));
+        Taps q;
+        if (VOL == VOL_B9U8) {
+            const uint8_t *b = reinterpret_cast<const uint8_t *>(V.data) + ((uint64_t)brick * 729u + local);
+            q.p00 = *reinterpret_cast<const u16_unaligned *>(b); q.p10 = *reinterpret_cast<const u16_unaligned *>(b + 9);
+            q.p01 = *reinterpret_cast<const u16_unaligned *>(b + 81); q.p11 = *reinterpret_cast<const u16_unaligned *>(b + 90);
+        } else {
+            const uint16_t *b = reinterpret_cast<const uint16_t *>(V.data) + ((uint64_t)brick * 729u + local);
+            q.p00 = *reinterpret_cast<const u32_unaligned *>(b); q.p10 = *reinterpret_cast<const u32_unaligned *>(b + 9);
+            q.p01 = *reinterpret_cast<const u32_unaligned *>(b + 81); q.p11 = *reinterpret_cast<const u32_unaligned *>(b + 90);
+        }
+        return q;
+    };
+    float fx, fy, fz;
+    Taps c0, c1;
+    {
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        c0 = request(ux, uy, uz);
+    }
+    auto trip = [&](const Taps &cur, Taps &nxt) -> bool {
+        if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; if (wave_leader()) { cs.w_outer++; cs.w_sample++; } }
+        px = px + sx; py = py + sy; pz = pz + sz;  // :118
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        nxt = request(ux, uy, uz);
+        float tp[8];
+        if (VOL == VOL_B9U8) {
+            tp[0] = (float)(cur.p00 & 0xffu); tp[1] = (float)(cur.p00 >> 8); tp[2] = (float)(cur.p10 & 0xffu); tp[3] = (float)(cur.p10 >> 8);
+            tp[4] = (float)(cur.p01 & 0xffu); tp[5] = (float)(cur.p01 >> 8); tp[6] = (float)(cur.p11 & 0xffu); tp[7] = (float)(cur.p11 >> 8);
+        } else {
+            tp[0] = h2f(cur.p00 & 0xffffu); tp[1] = h2f(cur.p00 >> 16); tp[2] = h2f(cur.p10 & 0xffffu); tp[3] = h2f(cur.p10 >> 16);
+            tp[4] = h2f(cur.p01 & 0xffffu); tp[5] = h2f(cur.p01 >> 16); tp[6] = h2f(cur.p11 & 0xffffu); tp[7] = h2f(cur.p11 >> 16);
+        }
+        const float c00 = fmaf(fx, tp[1] - tp[0], tp[0]), c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+        const float c01 = fmaf(fx, tp[5] - tp[4], tp[4]), c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
+        const float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
+        float v = fmaf(fz, l1 - l0, l0);
+        if (VOL == VOL_B9U8) v = v * (1.0f / 255.0f);
+        const float a = transfer_alpha(v);
+        constexpr double kk = 6.28318 / 6.283185307179586476925;
+        constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+        constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+        const float cr = __builtin_amdgcn_cosf(a * pc0);
+        const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+        const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+        const float w = (1.0f - A) * a;  // :112-114
+        Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
+        A = A + w;
+        t = t + dt;
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        return t < t1 && A < 0.95f;
+    };
+    for (;;) {
+        if (!trip(c0, c1)) break;
+        if (!trip(c1, c0)) break;
+    }
+    asm volatile("" ::"v"(c0.p00), "v"(c0.p10), "v"(c0.p01), "v"(c0.p11), "v"(c1.p00), "v"(c1.p10), "v"(c1.p01), "v"(c1.p11));
+    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+}
+
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
@@ -647,6 +724,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
+        else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);
         else march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
         A = r.A; Gr = r.Gr; Gg = r.Gg; Gb = r.Gb;
         Cr = linear_to_srgb(fmaf(0.5f, Gr, 0.5f * A));  // :121-123

@@ -9,8 +9,8 @@ root gathers the buffers and scatters them into its backbuffer (`vk_untile`).  R
 independent, so there is no reduction -- the gather is the only collective.  Tiles are interleaved
 (not contiguous strips) because ~70 % of a 16:9 frame misses the cube and opacity varies.
 
-Frames are pipelined: the gather of frame k runs on the collective's stream while frame k+1 is
-marched, and the root un-tiles frame k after launching frame k+1.
+Frames are pipelined in batches: the gather of batch g (several frames per collective call) runs on
+the collective's stream while batch g+1 is marched, and the root un-tiles batch g after launching g+1.
 """
 from __future__ import annotations
 
@@ -43,37 +43,54 @@ def n_slots(width: int, height: int, tile_size: int, world: int) -> int:
 
 
 class FrameGather:
-    """The collective half: fixed-size gather of every rank's compact tile buffer to `root`.
-    Device-agnostic (RCCL for cuda tensors, gloo for the CPU tests)."""
+    """The collective half: gather of every rank's compact tile buffers to `root`, `batch` frames per
+    collective.  Device-agnostic (RCCL for cuda tensors, gloo for the CPU tests).
 
-    def __init__(self, width: int, height: int, tile_size: int, channels_dtype, device, root: int = 0, group=None):
+    A collective call costs ~100 us of host time through torch.distributed -- more than a whole C2
+    frame takes to march on one GPU -- so frames are moved `batch` at a time: rank buffers are
+    [batch, n, ts, ts, 4] (n = active slots of the current camera), two sets, so batch g+1 is marched
+    while batch g is on the wire.  The root receives [world, batch, n, ts, ts, 4]."""
+
+    def __init__(self, width: int, height: int, tile_size: int, channels_dtype, device, root: int = 0, group=None, batch: int = 1):
         import torch
         import torch.distributed as dist
 
-        self.dist = dist
+        self.torch, self.dist = torch, dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.root = root
         self.ts = tile_size
+        self.batch = max(1, int(batch))
         self.slots = n_slots(width, height, tile_size, self.world)
-        shape = (self.slots, tile_size, tile_size, 4)
-        # two compact buffers: frame k+1 is rendered while frame k is in flight
-        self.compact = [torch.zeros(shape, dtype=channels_dtype, device=device) for _ in range(2)]
-        self.gathered = None
-        if self.rank == root:
-            self.gathered = [torch.zeros((self.world,) + shape, dtype=channels_dtype, device=device) for _ in range(2)]
-        self._views = {}  # (buffer, n_slots) -> (send view, [recv views]): slicing tensors costs microseconds per frame
+        self.dtype, self.device = channels_dtype, device
+        self._bufs = {}   # n -> (compact[2], gathered[2] or None)
+        self._views = {}  # (n, set, count) -> (send view, [recv views]): slicing tensors costs microseconds per frame
 
-    def start(self, k: int, n_slots: int | None = None):
-        """Launch the gather of the first `n_slots` slots of compact[k % 2] (async); returns the work
-        handle.  Slots beyond the active ones hold nothing worth moving (`Context.partition_active`)."""
-        n = self.slots if n_slots is None else min(n_slots, self.slots)
-        key = (k % 2, n)
+    def buffers(self, n: int | None = None):
+        """(compact sets, gathered sets) for n slots per frame (default: all slots)."""
+        n = self.slots if n is None else min(int(n), self.slots)
+        v = self._bufs.get(n)
+        if v is None:
+            torch = self.torch
+            shape = (self.batch, n, self.ts, self.ts, 4)
+            compact = [torch.zeros(shape, dtype=self.dtype, device=self.device) for _ in range(2)]
+            gathered = None
+            if self.rank == self.root:
+                gathered = [torch.zeros((self.world,) + shape, dtype=self.dtype, device=self.device) for _ in range(2)]
+            v = self._bufs[n] = (compact, gathered)
+        return v
+
+    def start(self, set_: int, n: int | None = None, count: int | None = None):
+        """Launch the gather of the first `count` frames of compact set `set_` (async); returns the work handle."""
+        n = self.slots if n is None else min(int(n), self.slots)
+        count = self.batch if count is None else count
+        key = (n, set_, count)
         v = self._views.get(key)
         if v is None:
-            buf = self.compact[k % 2][:n]
-            out = [self.gathered[k % 2][r, :n] for r in range(self.world)] if self.rank == self.root else None
+            compact, gathered = self.buffers(n)
+            buf = compact[set_][:count]
+            out = [gathered[set_][r, :count] for r in range(self.world)] if self.rank == self.root else None
             v = self._views[key] = (buf, out)
         buf, out = v
         if self.rank == self.root:
@@ -84,51 +101,115 @@ class FrameGather:
 class TileParallelRenderer:
     """March + gather + un-tile for one frame stream on this rank's GPU."""
 
-    def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, root: int = 0, group=None):
+    def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, root: int = 0, group=None, batch: int = 1,
+                 frames_in_flight: int = 1):
+        """`batch` frames travel per gather call; up to `frames_in_flight` of them are marched concurrently,
+        each on its own stream into its own slice of the batch buffer.  A rank's share of a small frame is a
+        few hundred waves whose length is set by the slowest one; overlapping consecutive frames is what keeps
+        the GPU busy (the reference, like any wgpu app, also keeps more than one frame in flight)."""
         import torch
 
         self.torch = torch
         self.ctx, self.pipe = ctx, pipeline
+        # The collective is ordered against torch's *current* stream; the march and the un-tile must run
+        # on that same stream or the gather could start before the tiles are written.
+        # (The legacy default stream has handle 0, which the C-ABI reads as "the context's own": drive
+        # the renderer inside `with torch.cuda.stream(s)` for a real stream s, as bench.py does.)
+        cur = torch.cuda.current_stream().cuda_stream
+        if not cur:
+            raise RuntimeError("TileParallelRenderer needs a non-default torch stream: create it inside `with torch.cuda.stream(torch.cuda.Stream())`")
+        if ctx.stream_handle != cur:
+            ctx.set_stream(cur)
+        self._stream = cur
         bb = ctx.render_backbuffer
         dtype = torch.float32 if bb.format == N.OUT_RGBA32F else torch.float16
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.fg = FrameGather(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group)
+        self.fg = FrameGather(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group, batch=batch)
         assert self.fg.slots == partition_slots(bb.width, bb.height, tile_size, self.fg.world)
-        self._pending = None  # (frame index, work) whose un-tile is still owed
+        self._esize = 4 if bb.format == N.OUT_RGBA32F else 2
+        self._pending = None  # (set, n, count, work) of the batch whose un-tile is still owed
         self._active, self._active_key = None, None
+        self._n = None        # active slots of the batch being filled
+        self._set, self._filled = 0, 0
+        self._fif = max(1, min(int(frames_in_flight), self.fg.batch))
+        self._main = torch.cuda.current_stream()
+        self._side, self._done, self._free = [], [], [None, None]
+        if self._fif > 1:
+            self._side = [torch.cuda.Stream() for _ in range(self._fif)]
+            self._done = [[torch.cuda.Event() for _ in range(self.fg.batch)] for _ in range(2)]  # frame b of set s marched
+            self._free = [None, None]  # set s may be overwritten once this event (recorded on the main stream) has passed
 
     @property
     def is_root(self) -> bool:
         return self.fg.rank == self.fg.root
 
-    def submit(self, k: int):
-        """Frame k: march this rank's tiles, start their gather; finish frame k-1 on the root."""
+    def submit(self, k: int = 0):
+        """Next frame: march this rank's tiles into the current batch; when the batch is full, start its
+        gather and finish the previous batch on the root.  (`k` is informational: frames are taken in call order.)"""
         fg = self.fg
-        self.pipe.record_partition(self.ctx, fg.ts, fg.rank, fg.world, fg.compact[k % 2].data_ptr())
-        if self._active_key != id(self.ctx) or self.ctx.camera.updated or self._active is None:
-            self._active = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)[1]  # per camera; cached in the library too
-            self._active_key = id(self.ctx)
-        n_slots = self._active
-        if n_slots == 0:
-            self._finish_pending()
-            self._pending = (k, None)
-            return
-        work = fg.start(k, n_slots)
+        if self.torch.cuda.current_stream().cuda_stream != self._stream:
+            raise RuntimeError("TileParallelRenderer must be driven on the torch stream it was created on")
+        key = (id(self.ctx), self.ctx.camera_epoch)
+        if self._active_key != key:
+            self._active = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)[1]  # per uploaded camera; cached in the library too
+            self._active_key = key
+        n = self._active
+        if self._n is not None and n != self._n and self._filled:
+            self._launch_batch()  # the camera changed the active set: close the batch at its old size
+        self._n = n
+        if n > 0:
+            compact, _ = fg.buffers(n)
+            frame_bytes = n * fg.ts * fg.ts * 4 * self._esize
+            dst = compact[self._set].data_ptr() + self._filled * frame_bytes
+            if self._fif > 1:
+                st = self._side[self._filled % self._fif]
+                if self._filled < self._fif:  # first use of this stream in the batch: the set must be free, the camera uploaded
+                    st.wait_stream(self._main) if self._free[self._set] is None else st.wait_event(self._free[self._set])
+                self.pipe.record_partition(self.ctx, fg.ts, fg.rank, fg.world, dst, stream=st.cuda_stream)
+                self._done[self._set][self._filled].record(st)
+            else:
+                self.pipe.record_partition(self.ctx, fg.ts, fg.rank, fg.world, dst)
+        self._filled += 1
+        if self._filled == fg.batch:
+            self._launch_batch()
+
+    def _launch_batch(self):
+        fg, n, count, set_ = self.fg, self._n, self._filled, self._set
+        if self._fif > 1 and n > 0:
+            for b in range(count):
+                self._main.wait_event(self._done[set_][b])  # the gather (ordered after the main stream) sees every frame
+        work = fg.start(set_, n, count) if n > 0 else None
         self._finish_pending()
-        self._pending = (k, work)
+        self._pending = (set_, n, count, work)
+        self._set, self._filled = set_ ^ 1, 0
 
     def _finish_pending(self):
         if self._pending is None:
             return
-        k, work = self._pending
+        set_, n, count, work = self._pending
         if work is not None:
             work.wait()  # orders the current stream after the collective
+        if self._fif > 1:
+            ev = self._free[set_] or self.torch.cuda.Event()
+            ev.record(self._main)  # the send buffers of this set are free from here on
+            self._free[set_] = ev
         if self.is_root:
-            N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, self.fg.gathered[k % 2].data_ptr(), self.fg.ts,
-                                                      self.fg.world, self.fg.slots))
+            fg = self.fg
+            if n > 0:
+                base = fg.buffers(n)[1][set_].data_ptr()
+                frame_bytes = n * fg.ts * fg.ts * 4 * self._esize
+                for b in range(count):  # every frame of the batch materialises in the root's backbuffer, in order
+                    N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, base + b * frame_bytes, fg.ts, fg.world, fg.batch * n))
+            else:
+                # no tile touches the cube: the un-tile only clears (it reads no slot), once per frame
+                dummy = fg.buffers(1)[1][0].data_ptr()
+                for _ in range(count):
+                    N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, dummy, fg.ts, fg.world, fg.batch))
         self._pending = None
 
     def flush(self):
+        if self._filled:
+            self._launch_batch()
         self._finish_pending()
 
 
