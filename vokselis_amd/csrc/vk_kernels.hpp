@@ -12,10 +12,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef VK_EAGER_CELL
-#define VK_EAGER_CELL 1
-#endif
-
 namespace vk {
 
 // ---- layouts ---------------------------------------------------------------------------------
@@ -418,8 +414,6 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
             const int bx = ix >> 2, by = iy >> 2, bz = iz >> 2;
             const char *cptr = nullptr;
             uint32_t d = 0, coff = 0;
-            CellBits<VOL> cb_eager;
-            cb_eager.v = 0;
             if (SAFE) {
                 int64_t off = (int64_t)bz * (int64_t)V.kz + (int64_t)(by * (int)V.ky + bx * (int)V.kx) +
                               (int64_t)((iz << V.sh_z) + (iy << V.sh_y) + (ix << V.sh_x)) + (int64_t)V.c0;
@@ -431,7 +425,6 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 const uint32_t idx = lut[ix + 2] + luty[iy + 2] + lutz[iz + 2];
                 coff = SKIP ? (uint32_t)(idx << V.sh_x) : idx;
                 if (SKIP) d = V.dist[idx + doff];
-                if (SKIP && VK_EAGER_CELL) cb_eager = load_cell<VOL>(cells, coff);  // requested with the distance, not after it
             }
             if (SKIP && d != 0) {
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
@@ -475,15 +468,12 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     t = t + dt;
                     if (COUNT) { n_iter++; }
                 }
-                if (!SAFE && VK_EAGER_CELL) asm volatile("" ::"v"(cb_eager.v));  // a use on this path too: the request stays ahead of the branch
                 continue;
             }
             CellBits<VOL> cb;
             if (SAFE) {
                 if constexpr (VOL == VOL_P8) { const uint2 c = *reinterpret_cast<const uint2 *>(cptr); cb.v.x = c.x; cb.v.y = c.y; }
                 else { const uint4 c = *reinterpret_cast<const uint4 *>(cptr); cb.v.x = c.x; cb.v.y = c.y; cb.v.z = c.z; cb.v.w = c.w; }
-            } else if (SKIP && VK_EAGER_CELL) {
-                cb = cb_eager;
             } else {
                 cb = load_cell<VOL>(cells, coff);
             }
