@@ -285,6 +285,24 @@ def main():
                     cx.close()
             except Exception as e:  # a side measurement must not take the headline down
                 extras["xor_compute_nearest_720p"] = {"error": str(e)}
+            # C3: the procedural (no volume) configuration at 1920x1080, xor camera -- ALU work only:
+            # 24 specified sines (f64 Cody-Waite, ~45 f64 ops each) + ~200 f32 flops per step, 0 volume bytes
+            try:
+                cam3 = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H)
+                cp = V.Context(W, H, cam3, device=local_rank, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+                try:
+                    cp.set_camera_blob(cam3.get_proj_view_matrix())  # Uniform.time stays 0, as the reference runs xor.wgsl
+                    cp.reset_step_counts()
+                    V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_COUNT).record(cp)
+                    sr, _ = cp.step_counts()
+                    ms = time_launches(cp, V.RaycastPipeline(V.MODE_PROCEDURAL), 5, warm=1)
+                    extras["c3_procedural_1080p"] = {"launch_ms": ms, "s_ref": sr, "Mray_steps_per_s": sr / ms / 1e3,
+                                                     "Gsines_per_s": 24 * sr / ms / 1e6, "f64_ops_per_step_est": 24 * 45,
+                                                     "f32_ops_per_step_est": 200, "volume_bytes_per_step": 0}
+                finally:
+                    cp.close()
+            except Exception as e:
+                extras["c3_procedural_1080p"] = {"error": str(e)}
             out["extras"] = extras
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

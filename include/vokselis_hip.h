@@ -40,7 +40,15 @@ enum vk_status {
 enum vk_volume_format { VK_FMT_R8_UNORM = 0, VK_FMT_R16_FLOAT = 1, VK_FMT_RGBA16F_PAIR = 2 };
 
 /* raycast_naive.wgsl fs_main vs raycast_compute.wgsl render()/get_col2 */
-enum vk_mode { VK_MODE_NAIVE_TRILINEAR = 0, VK_MODE_COMPUTE_NEAREST = 1 };
+enum vk_mode {
+    VK_MODE_NAIVE_TRILINEAR = 0,
+    VK_MODE_COMPUTE_NEAREST = 1,
+    /* SURVEY 8(d) C3, "procedural, no volume texture": the reference has no such example (examples/trig draws one
+     * triangle); this build defines it as the compute twin's ray and march (raycast_compute.wgsl:62-131) with the
+     * texel loads replaced by the xor example's density function noise_volume(p / 2) (shaders/xor.wgsl:55-61,
+     * un.time = the uploaded Uniform's time), colour = density.rgb / 2, no normals.  Needs no volume. */
+    VK_MODE_PROCEDURAL = 2
+};
 
 /* src/context/hdr_backbuffer.rs:10 is rgba16float; RGBA32F is the parity surface. */
 enum vk_out_format { VK_OUT_RGBA32F = 0, VK_OUT_RGBA16F = 1 };

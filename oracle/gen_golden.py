@@ -102,6 +102,16 @@ def main():
                         rgba=rgba, steps=steps.astype(np.uint16), tile_rgba=t_rgba, tile_steps=t_steps.astype(np.uint16))
     print(f"compute: S = {int(steps.sum())}, hit = {(steps > 0).mean():.3f}")
 
+    # ---- procedural density (C3): no volume, the compute march over xor.wgsl's noise_volume ----------
+    Wp, Hp = 96, 54
+    p_rgba, p_steps = R.render_procedural(cams["xor_16x9"], Wp, Hp)
+    cp_rgba, cp_steps = O.render_procedural(cams["xor_16x9"], Wp, Hp)
+    assert np.abs(p_rgba - cp_rgba).max() <= 1e-6 and (p_steps == cp_steps).all()
+    h_rgba, h_steps = R.render_procedural(cams["xor_16x9"], Wp, Hp, dt_scale=2.5)
+    np.savez_compressed(os.path.join(OUT, "procedural_96x54.npz"), rgba=p_rgba, steps=p_steps.astype(np.uint16),
+                        rgba_dt2p5=h_rgba, steps_dt2p5=h_steps.astype(np.uint16))
+    print(f"procedural: S = {int(p_steps.sum())}, hit = {(p_steps > 0).mean():.3f}")
+
     # ---- unit vectors --------------------------------------------------------------------
     o = np.array([[-0.2385, 0.0206, 0.0258], [0.5, 0.5, -1.0], [0.5, 0.5, 0.5], [2.0, 2.0, 2.0], [0.25, 0.75, -3.0]], np.float32)
     d = np.array([[0.7, 0.5, 0.5], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 1.0, 1.0], [0.0, 0.0, 1.0]], np.float32)

@@ -283,6 +283,103 @@ def render_compute(camera_blob: bytes, density: np.ndarray, normals: np.ndarray,
 
 
 # ------------------------------------------------------------------------------------------------
+# C3: procedural density, no volume -- the compute twin's march over shaders/xor.wgsl:18-61
+
+
+def _xor_hash(h):
+    """xor.wgsl:18-20, fract(sin(h) * 43758.5453123); the sine is numpy's float64 sine rounded to f32 (the C
+    oracle uses its own f64 Cody-Waite evaluation: the two agree wherever neither sits on a rounding tie)."""
+    s = np.sin(h.astype(np.float64)).astype(np.float32)
+    v = (s * f32(43758.5453123)).astype(np.float32)
+    return (v - np.floor(v)).astype(np.float32)
+
+
+def _xor_mix(a, b, t):
+    return ((a * (f32(1.0) - t).astype(np.float32)).astype(np.float32) + (b * t).astype(np.float32)).astype(np.float32)
+
+
+def _xor_noise(x):
+    p = [np.floor(v).astype(np.float32) for v in x]
+    f = [(v - np.floor(v)).astype(np.float32) for v in x]
+    f = [((v * v).astype(np.float32) * (f32(3.0) - (f32(2.0) * v).astype(np.float32)).astype(np.float32)).astype(np.float32) for v in f]
+    n = ((p[0] + (p[1] * f32(157.0)).astype(np.float32)).astype(np.float32) + (f32(113.0) * p[2]).astype(np.float32)).astype(np.float32)
+    h = lambda o: _xor_hash((n + f32(o)).astype(np.float32))
+    return _xor_mix(_xor_mix(_xor_mix(h(0.0), h(1.0), f[0]), _xor_mix(h(157.0), h(158.0), f[0]), f[1]),
+                    _xor_mix(_xor_mix(h(113.0), h(114.0), f[0]), _xor_mix(h(270.0), h(271.0), f[0]), f[1]), f[2])
+
+
+def _xor_fbm(p):
+    f = (f32(0.5) * _xor_noise(p)).astype(np.float32)
+    p = [(v * f32(2.01)).astype(np.float32) for v in p]
+    f = (f + (f32(0.25) * _xor_noise(p)).astype(np.float32)).astype(np.float32)
+    p = [(v * f32(2.02)).astype(np.float32) for v in p]
+    return (f + (f32(0.125) * _xor_noise(p)).astype(np.float32)).astype(np.float32)
+
+
+def xor_noise_volume(c, time=0.0):
+    """xor.wgsl:55-61 -> (val, alpha) at generator coordinates c (three f32 arrays)."""
+    off = (f32(1.0), (np.sin(np.float64(f32(time))).astype(np.float32) * f32(0.1)).astype(np.float32), f32(21.0))
+    pos = [((c[i] + off[i]).astype(np.float32) * f32(32.0)).astype(np.float32) for i in range(3)]
+    val = _xor_fbm(pos)
+    ln = np.sqrt((((c[0] * c[0]).astype(np.float32) + (c[1] * c[1]).astype(np.float32)).astype(np.float32) + (c[2] * c[2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    return val, (val * _smoothstep(0.5, 0.25, ln)).astype(np.float32)
+
+
+def render_procedural(camera_blob: bytes, W: int, H: int, dt_scale: float = 1.0, time: float = 0.0):
+    """vo_render(mode=PROCEDURAL): render()/get_col2() of raycast_compute.wgsl with the texel loads replaced by
+    noise_volume(p/2), colour = density.rgb/2, no normals.  Returns (rgba [H,W,4] f32, steps [H,W] u32)."""
+    cam = np.frombuffer(camera_blob, np.float32)
+    inv_proj = cam[20:36]
+    X, Y = np.meshgrid(np.arange(W), np.arange(H))
+    cx, cy = X.astype(np.float32).ravel(), Y.astype(np.float32).ravel()
+    dx, dy = f32(W), f32(H)
+    sx = ((f32(2.0) * cx) / dx - f32(1.0)).astype(np.float32)
+    sy = ((f32(2.0) * cy) / dy - f32(1.0)).astype(np.float32)
+    sy = (sy * -(dy / dx)).astype(np.float32)
+    zero, one = np.zeros_like(sx), np.ones_like(sx)
+    vp = _mat_vec(inv_proj, [sx, sy, zero, one])
+    vt = _mat_vec(inv_proj, [sx, sy, one, one])
+    eye = [(vp[i] / vp[3]).astype(np.float32) for i in range(3)]
+    d = _normalize([((vt[i] / vt[3]).astype(np.float32) - eye[i]).astype(np.float32) for i in range(3)])
+    clear = (f32(0.023), f32(0.02), f32(0.02))
+    t0, t1 = intersect_box(eye, d, -1.0, 1.0)
+    with np.errstate(invalid="ignore"):
+        hit = t0 < t1
+    t0 = np.fmax(t0, f32(0.0))
+    with np.errstate(divide="ignore"):
+        dtv = [(f32(1.0) / (f32(256.0) * np.abs(d[i])).astype(np.float32)).astype(np.float32) for i in range(3)]
+    dt = (f32(dt_scale) * np.fmax(np.fmin(dtv[0], np.fmin(dtv[1], dtv[2])), f32(0.01))).astype(np.float32)
+    n = sx.size
+    C = [np.full(n, clear[k], np.float32) for k in range(3)]
+    A = np.full(n, f32(0.1), np.float32)
+    t = t0.copy()
+    nst = np.zeros(n, np.uint32)
+    with np.errstate(invalid="ignore"):
+        active = hit & (t < t1)
+    while active.any():
+        idx = np.nonzero(active)[0]
+        p = [(eye[i][idx] + (t[idx] * d[i][idx]).astype(np.float32)).astype(np.float32) for i in range(3)]
+        val, alpha = xor_noise_volume([(v * f32(0.5)).astype(np.float32) for v in p], time)
+        nst[idx] += 1
+        vc = (val / f32(2.0)).astype(np.float32)
+        va = _smoothstep(0.0, 0.7, ((alpha * alpha).astype(np.float32) * alpha).astype(np.float32))
+        w = ((f32(1.0) - A[idx]) * va).astype(np.float32)
+        for k in range(3):
+            C[k][idx] = (C[k][idx] + (w * vc).astype(np.float32)).astype(np.float32)
+        A[idx] = (A[idx] + w).astype(np.float32)
+        done = A[idx] >= f32(0.95)
+        cont = idx[~done]
+        t[cont] = (t[cont] + dt[cont]).astype(np.float32)
+        active[idx[done]] = False
+        active[cont] = t[cont] < t1[cont]
+    out = np.zeros((n, 4), np.float32)
+    for k in range(3):
+        out[:, k] = np.where(hit, C[k], clear[k])
+    out[:, 3] = 1.0
+    return out.reshape(H, W, 4), nst.reshape(H, W)
+
+
+# ------------------------------------------------------------------------------------------------
 # deterministic volumes (integer-only; must be bit-identical to vo_volume_* in the C oracle)
 
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libvokselis_oracle.so")
 
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
-MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST = 0, 1
+MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST, MODE_PROCEDURAL = 0, 1, 2
 FLAG_NO_EARLY_OUT, FLAG_TAPNORM_PER_TAP = 1, 2
 
 
@@ -44,6 +44,7 @@ class RenderArgs(C.Structure):
         ("out_rgba", C.c_void_p),
         ("out_steps", C.c_void_p),
         ("out_sampled", C.c_void_p),
+        ("proc_time", C.c_float),
     ]
 
 
@@ -120,6 +121,26 @@ def camera_blob(zoom, pitch, yaw, target, aspect) -> bytes:
 def camera_from_blob(blob: bytes) -> CameraUniform:
     assert len(blob) == 144
     return CameraUniform.from_buffer_copy(blob)
+
+
+def render_procedural(camera: bytes, width: int, height: int, *, dt_scale: float = 1.0, time: float = 0.0, tile=None,
+                      flags: int = 0, threads: int = 0):
+    """C3: the compute twin's march over the xor example's density function, no volume (pixel_procedural)."""
+    cu = camera_from_blob(camera)
+    rgba = np.zeros((height, width, 4), np.float32)
+    steps = np.zeros((height, width), np.uint32)
+    a = RenderArgs()
+    a.camera = C.pointer(cu)
+    a.mode = MODE_PROCEDURAL
+    a.width, a.height = width, height
+    tx, ty, tw, th = (0, 0, width, height) if tile is None else tile
+    a.tile_x, a.tile_y, a.tile_w, a.tile_h = tx, ty, tw, th
+    a.dt_scale, a.flags, a.threads, a.proc_time = dt_scale, flags, threads, time
+    a.out_rgba, a.out_steps = rgba.ctypes.data, steps.ctypes.data
+    rc = lib().vo_render(C.byref(a))
+    if rc != 0:
+        raise RuntimeError(f"vo_render failed: {rc}")
+    return rgba, steps
 
 
 def render(camera: bytes, volume: np.ndarray, width: int, height: int, *, dt_scale: float = 1.0,

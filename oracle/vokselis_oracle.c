@@ -435,6 +435,46 @@ static inline int trunc_i32(float f) {
     return (int)f;
 }
 
+static void xor_noise_volume(const float c[3], float time, float out[4]);
+
+/* C3: the "procedural, no volume texture" configuration.  The reference has no such example
+ * (F4); this build defines it as the compute twin's ray and march (render/get_col2, raycast_compute.wgsl:62-131)
+ * with the two texel loads replaced by the xor example's own density function evaluated at the sample
+ * position, `noise_volume(p / 2)` (shaders/xor.wgsl:55-61; p/2 is the generator's coordinate of that point),
+ * and no normals: colour = density.rgb / 2 unshaded.  24 specified sines + ~200 flops per step, 0 bytes. */
+static void pixel_procedural(const vo_render_args *a, uint32_t gx, uint32_t gy, float out[4], uint32_t *steps) {
+    float eye[3], dir[3], th[2];
+    vo_ray_compute(a->camera, a->width, a->height, (float)gx, (float)gy, eye, dir);
+    const float clear[3] = {0.023f, 0.02f, 0.02f};
+    *steps = 0;
+    vo_intersect_box(eye, dir, -1.0f, 1.0f, th);
+    out[0] = clear[0]; out[1] = clear[1]; out[2] = clear[2]; out[3] = 1.0f;
+    if (!(th[0] < th[1])) return;
+    th[0] = vmax(th[0], 0.0f);
+    float C[3] = {clear[0], clear[1], clear[2]}, A = 0.1f;
+    const float bs = 256.0f; /* the literal grid of the xor example (examples/xor/main.rs) */
+    float dtx = 1.0f / (bs * fabsf(dir[0])), dty = 1.0f / (bs * fabsf(dir[1])), dtz = 1.0f / (bs * fabsf(dir[2]));
+    const float dt = a->dt_scale * vmax(vmin(dtx, vmin(dty, dtz)), 0.01f);
+    uint32_t n = 0;
+    for (float t = th[0]; t < th[1]; t = t + dt) {
+        const float p[3] = {eye[0] + t * dir[0], eye[1] + t * dir[1], eye[2] + t * dir[2]};
+        const float c[3] = {p[0] * 0.5f, p[1] * 0.5f, p[2] * 0.5f};
+        float vol[4];
+        xor_noise_volume(c, a->proc_time, vol);
+        n++;
+        const float vc = vol[0] / 2.0f;
+        float va = (vol[3] * vol[3]) * vol[3];
+        va = smoothstepf(0.0f, 0.7f, va);
+        const float w = (1.0f - A) * va;
+        for (int k = 0; k < 3; k++) C[k] = C[k] + w * vc;
+        A = A + w;
+        if (A >= 0.95f && !(a->flags & VO_FLAG_NO_EARLY_OUT)) break;
+        if (!(dt > 0.0f)) break;
+    }
+    out[0] = C[0]; out[1] = C[1]; out[2] = C[2];
+    *steps = n;
+}
+
 static void pixel_compute(const vo_render_args *a, uint32_t gx, uint32_t gy, float out[4], uint32_t *steps) {
     /* coord = global_id + offset (:102); the tile offset is already folded into (gx,gy) */
     float eye[3], dir[3], th[2];
@@ -502,8 +542,9 @@ static void pixel_compute(const vo_render_args *a, uint32_t gx, uint32_t gy, flo
 /* ------------------------------------------------------------------------- */
 
 int vo_render(const vo_render_args *a) {
-    if (!a || !a->camera || !a->volume || !a->out_rgba) return -1;
-    if (a->nx == 0 || a->ny == 0 || a->nz == 0 || a->width == 0 || a->height == 0) return -1;
+    if (!a || !a->camera || !a->out_rgba) return -1;
+    if (a->mode != VO_MODE_PROCEDURAL && (!a->volume || a->nx == 0 || a->ny == 0 || a->nz == 0)) return -1;
+    if (a->width == 0 || a->height == 0) return -1;
     if (a->mode == VO_MODE_NAIVE_TRILINEAR && a->format != VO_FMT_R8_UNORM && a->format != VO_FMT_R16_FLOAT)
         return -2;
     if (a->mode == VO_MODE_COMPUTE_NEAREST && (a->format != VO_FMT_RGBA16F_PAIR || !a->volume2)) return -2;
@@ -523,7 +564,10 @@ int vo_render(const vo_render_args *a) {
             uint32_t st = 0, sm = 0;
             if (a->mode == VO_MODE_NAIVE_TRILINEAR)
                 pixel_naive(a, (uint32_t)x, (uint32_t)y, a->out_rgba + 4 * pix, &st, &sm);
-            else {
+            else if (a->mode == VO_MODE_PROCEDURAL) {
+                pixel_procedural(a, (uint32_t)x, (uint32_t)y, a->out_rgba + 4 * pix, &st);
+                sm = st;
+            } else {
                 pixel_compute(a, (uint32_t)x, (uint32_t)y, a->out_rgba + 4 * pix, &st);
                 sm = st;
             }

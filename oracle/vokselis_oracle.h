@@ -50,7 +50,7 @@ typedef struct vo_uniform {
 } vo_uniform;
 
 enum { VO_FMT_R8_UNORM = 0, VO_FMT_R16_FLOAT = 1, VO_FMT_RGBA16F_PAIR = 2 };
-enum { VO_MODE_NAIVE_TRILINEAR = 0, VO_MODE_COMPUTE_NEAREST = 1 };
+enum { VO_MODE_NAIVE_TRILINEAR = 0, VO_MODE_COMPUTE_NEAREST = 1, VO_MODE_PROCEDURAL = 2 /* no volume, see pixel_procedural */ };
 
 /* Flags for vo_render. */
 enum {
@@ -74,6 +74,7 @@ typedef struct vo_render_args {
     float *out_rgba;             /* [height][width][4] f32, only tile pixels written */
     uint32_t *out_steps;         /* optional [height][width]: loop iterations executed */
     uint32_t *out_sampled;       /* optional: iterations with at least one tap > 25 (u8) */
+    float proc_time;             /* PROCEDURAL: un.time of noise_volume (the reference runs it at 0) */
 } vo_render_args;
 
 /* Camera::new + fix_eye + build_projection_view_matrix + get_proj_view_matrix

@@ -46,6 +46,23 @@ def test_oracle_matches_golden_compute(O, golden, cameras):
     assert np.allclose(rgba[miss][:, :3], [0.023, 0.02, 0.02]) and (rgba[..., 3] == 1).all()
 
 
+def test_oracle_matches_golden_procedural(O, R, golden, cameras):
+    """C3 (no volume): the compute march over xor.wgsl's noise_volume -- C oracle vs the numpy-made fixture, and
+    the two restatements on a fresh camera / time (their sines are evaluated independently)."""
+    g = golden["procedural_96x54"]
+    rgba, steps = O.render_procedural(cameras["xor_16x9"], 96, 54)
+    assert np.abs(rgba - g["rgba"]).max() <= 1e-6 and (steps == g["steps"]).all()
+    rgba, steps = O.render_procedural(cameras["xor_16x9"], 96, 54, dt_scale=2.5)
+    assert np.abs(rgba - g["rgba_dt2p5"]).max() <= 1e-6 and (steps == g["steps_dt2p5"]).all()
+    assert 0.1 < (steps > 0).mean() < 0.3 and steps.max() <= 347     # <= 2*sqrt(3)/0.01 steps through [-1,1]^3
+    miss = steps == 0
+    assert np.allclose(rgba[miss][:, :3], [0.023, 0.02, 0.02]) and (rgba[..., 3] == 1).all()
+    cam = O.camera_blob(2.2, 0.3, 2.0, (0.1, -0.1, 0.0), 4 / 3)
+    a, sa = O.render_procedural(cam, 40, 30, time=1.25)
+    b, sb = R.render_procedural(cam, 40, 30, time=1.25)
+    assert np.abs(a - b).max() <= 1e-5 and (sa != sb).mean() <= 0.01
+
+
 def test_two_restatements_agree_on_fresh_inputs(O, R):
     """Inputs that are not in the fixtures: other sizes, non-cubic dims, other cameras / dt."""
     for dims, cam_args, W, H, dt in [((40, 64, 24), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.5), 60, 40, 1.0),

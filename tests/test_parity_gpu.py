@@ -348,6 +348,44 @@ def test_compute_nearest_mode(V, O, golden, cameras):
         ctx.close()
 
 
+def test_procedural_mode(V, O, golden, cameras):
+    """C3: no volume, density from xor.wgsl's noise_volume at the sample position.  Trip counts are
+    integer work and must be identical; RGBA within 1e-4 (measured ~1e-7: the specified sine is shared)."""
+    g = golden["procedural_96x54"]
+    ctx = V.Context(96, 54, backbuffer=(96, 54), out_format=V.OUT_RGBA32F)
+    try:
+        ctx.set_camera_blob(cameras["xor_16x9"])          # no volume uploaded, Uniform.time = 0
+        for dt, kr, ks in ((1.0, "rgba", "steps"), (2.5, "rgba_dt2p5", "steps_dt2p5")):
+            ctx.reset_step_counts()
+            V.RaycastPipeline(V.MODE_PROCEDURAL, dt_scale=dt, flags=V.RENDER_COUNT).record(ctx)
+            img, steps = ctx.read_backbuffer(), ctx.read_steps()
+            assert (steps == g[ks]).all()
+            assert np.abs(img - g[kr]).max() <= TOL
+            assert ctx.step_counts()[0] == int(g[ks].astype(np.int64).sum())
+        # a tile that hangs off the image, uninstrumented, against the oracle at the same time value
+        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+        V.RaycastPipeline(V.MODE_PROCEDURAL).record(ctx, (64, 32, 64, 64))
+        ref, _ = O.render_procedural(cameras["xor_16x9"], 96, 54, tile=(64, 32, 64, 64))
+        img = ctx.read_backbuffer()
+        assert np.abs(img[32:, 64:] - ref[32:, 64:]).max() <= TOL
+    finally:
+        ctx.close()
+    # larger frame, other camera, nonzero Uniform.time (xor.wgsl's un.time)
+    W, H = 320, 180
+    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H)
+    ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        ctx.global_uniform.time = 0.75
+        V.native.check(ctx.handle, V.native.lib().vk_set_uniform(ctx.handle, ctx.global_uniform.to_bytes()))
+        ctx.set_camera_blob(cam.get_proj_view_matrix())
+        V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_COUNT).record(ctx)
+        img, steps = ctx.read_backbuffer(), ctx.read_steps()
+        ref, rsteps = O.render_procedural(cam.get_proj_view_matrix(), W, H, time=0.75)
+        assert (steps == rsteps).all() and np.abs(img - ref).max() <= TOL
+    finally:
+        ctx.close()
+
+
 def test_error_behaviour(V, O, cameras, golden_volumes):
     ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
     try:

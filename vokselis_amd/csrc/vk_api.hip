@@ -609,7 +609,7 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     auto mul = [&](const float *m, double x, double y, double z, double w, double o[4]) {
         for (int r = 0; r < 4; r++) o[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
     };
-    const double dims[3] = {(double)ctx->nx, (double)ctx->ny, (double)ctx->nz};
+    const double dims[3] = {(double)std::max(ctx->nx, 1u), (double)std::max(ctx->ny, 1u), (double)std::max(ctx->nz, 1u)};
     for (uint32_t j = 0; j < ty; j++)
         for (uint32_t i = 0; i < tx; i++) {
             double c = 0.0;
@@ -696,10 +696,12 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
 static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
                          uint32_t rank, uint32_t nranks, float dt_scale, uint32_t flags, void *compact_out) {
     if (!ctx) return VK_ERR_INVALID;
-    if (ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "render: no volume uploaded");
+    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "unknown mode");
+    if (ctx->format < 0 && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "render: no volume uploaded");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "render: no backbuffer (vk_backbuffer_resize)");
     if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "render: no camera (vk_set_camera)");
-    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST) return fail(ctx, VK_ERR_INVALID, "unknown mode");
+    // PROCEDURAL shares the compute twin's ray, box and step: geometry helpers treat it as that mode
+    const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
     if (mode == VK_MODE_NAIVE_TRILINEAR && ctx->format == VK_FMT_RGBA16F_PAIR)
         return fail(ctx, VK_ERR_INVALID, "NAIVE_TRILINEAR needs a scalar volume (R8_UNORM / R16_FLOAT)");
     if (mode == VK_MODE_COMPUTE_NEAREST && ctx->format != VK_FMT_RGBA16F_PAIR)
@@ -713,7 +715,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     {
         const float *e = ctx->camera;
         float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
-        if (mode == VK_MODE_COMPUTE_NEAREST) reach += 200.0f;  // near-plane point of a far=100 frustum
+        if (geo_mode == VK_MODE_COMPUTE_NEAREST) reach += 200.0f;  // near-plane point of a far=100 frustum
         float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
         float dt_min = mode == VK_MODE_NAIVE_TRILINEAR ? dt_scale / nmax : dt_scale * 0.01f;
         float ulp = std::nextafter(reach, 2.0f * reach) - reach;
@@ -735,12 +737,12 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.tiles_y = (rh + ts - 1) / ts;
     {
         int32_t cr[4];
-        cull_rect(ctx, mode, cr);
+        cull_rect(ctx, geo_mode, cr);
         L.cull_x0 = cr[0]; L.cull_y0 = cr[1]; L.cull_x1 = cr[2]; L.cull_y1 = cr[3];
     }
     L.rank = rank; L.nranks = nranks;
     {
-        int orc = tile_order_update(ctx, mode, ox, oy, rw, rh, ts, dt_scale);
+        int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts, dt_scale);
         if (orc) return orc;
         L.tile_order = ctx->d_order;
     }
@@ -779,7 +781,19 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
     const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
-    if (mode == VK_MODE_COMPUTE_NEAREST && ctx->vol_kind == VOL_PAIRB) {
+    if (mode == VK_MODE_PROCEDURAL) {
+        float time = 0.0f;
+        std::memcpy(&time, ctx->uniform + 36, sizeof(float));  // Uniform.time (global_ubo.rs:52-65), what xor.wgsl reads as un.time
+        if (!std::isfinite(time)) return fail(ctx, VK_ERR_INVALID, "Uniform.time must be finite");
+        const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+        if (f16) {
+            if (count) hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+            else hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+        } else {
+            if (count) hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA32F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+            else hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+        }
+    } else if (mode == VK_MODE_COMPUTE_NEAREST && ctx->vol_kind == VOL_PAIRB) {
         const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
         const uint32_t lds = pair_lut_entries(V.nx, V.ny, V.nz) * 4u;
         if (f16) {

@@ -1272,6 +1272,63 @@ __global__ __launch_bounds__(256) void xor_generate_kernel(uint2 *__restrict__ d
     normals[id] = nv.u;
 }
 
+// ---- PROCEDURAL: the compute twin's ray and march with the texel loads replaced by the xor
+// example's density function at the sample position, noise_volume(p / 2) (shaders/xor.wgsl:55-61), colour =
+// density.rgb / 2, no normals -- mirrors pixel_procedural of the oracle operation for operation.  No volume,
+// no loads: 24 specified sines (f64 Cody-Waite, ~45 f64 operations each) and ~200 f32 flops per step.
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDesc L, float time) {
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;
+    const PixelMap pm = map_pixel(L, lb, threadIdx.x);
+    if (!pm.valid) return;
+    float dimx = (float)L.W, dimy = (float)L.H;
+    float aspect_ratio = dimy / dimx;
+    float scx = 2.0f * (float)pm.x / dimx - 1.0f;
+    float scy = 2.0f * (float)pm.y / dimy - 1.0f;
+    scy = scy * -aspect_ratio;
+    float vp[4], vt[4];
+    mat4_mul_vec4(L.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(L.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
+    float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
+    normalize3(dir[0], dir[1], dir[2]);
+    float C[3] = {0.023f, 0.02f, 0.02f};
+    uint32_t n_iter = 0;
+    float t0, t1;
+    intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
+    if (t0 < t1) {
+        t0 = fmaxf(t0, 0.0f);
+        float A = 0.1f;
+        const float bs = 256.0f;
+        float dtx = 1.0f / (bs * fabsf(dir[0])), dty = 1.0f / (bs * fabsf(dir[1])), dtz = 1.0f / (bs * fabsf(dir[2]));
+        const float dt = L.dt_scale * fmaxf(fminf(dtx, fminf(dty, dtz)), 0.01f);
+        const float off1 = sin_spec(time * 1.0f) * 0.1f;
+        for (float t = t0; t < t1; t = t + dt) {
+            const float px = eye[0] + t * dir[0], py = eye[1] + t * dir[1], pz = eye[2] + t * dir[2];
+            float val, alpha;
+            xor_noise_volume(px * 0.5f, py * 0.5f, pz * 0.5f, off1, val, alpha);
+            n_iter++;
+            const float vc = val / 2.0f;
+            float va = (alpha * alpha) * alpha;
+            va = smoothstepf(0.0f, 0.7f, va);
+            const float w = (1.0f - A) * va;
+            C[0] = C[0] + w * vc; C[1] = C[1] + w * vc; C[2] = C[2] + w * vc;
+            A = A + w;
+            if (A >= 0.95f) break;
+            if (!(dt > 0.0f)) break;
+        }
+    }
+    store_pixel<OUT>(L.out, pm.out_index, C[0], C[1], C[2], 1.0f);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+        }
+    }
+}
+
 template <int OUT>
 __global__ __launch_bounds__(256) void clear_kernel(void *out, uint64_t n_px) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
