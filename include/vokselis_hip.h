@@ -59,8 +59,11 @@ enum vk_layout {
     VK_LAYOUT_LINEAR = 1, /* x-fastest as uploaded; 8 scalar taps per sample (validation kernel) */
     VK_LAYOUT_PACKED = 2, /* 4^3-bricked cells, each holding its 8 trilinear taps (+ per-octant skip maps) */
     VK_LAYOUT_PACKED_PAIRS = 3, /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
-    VK_LAYOUT_BRICKED = 4 /* dense 8^3 bricks + 1-voxel apron (9^3): 1.42x the dense bytes, 8 taps from one
-                             brick; for volumes far larger than the caches (no skip map) */
+    VK_LAYOUT_BRICKED = 4, /* dense 8^3 bricks + 1-voxel apron (9^3): 1.42x the dense bytes, 8 taps from one
+                              brick as four x-pair loads; the most compact layout (no skip map) */
+    VK_LAYOUT_QUADS = 5 /* every element holds a voxel's 2x2 (y,z) neighbourhood: 8 taps = two consecutive elements
+                           = ONE 8/16-byte load; 4.5x the dense bytes; pays when the image has more rays than the volume has
+                           voxel columns (no skip map; never AUTO's choice) */
 };
 
 enum vk_render_flags {

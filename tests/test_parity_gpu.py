@@ -53,7 +53,7 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
 
 
 def layouts(V):
-    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED}
+    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED, "Q": V.LAYOUT_QUADS}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -249,7 +249,7 @@ def test_tile_parallel_renderer_over_rccl_world1(V, O):
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)
-    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR, V.LAYOUT_BRICKED):
+    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR, V.LAYOUT_BRICKED, V.LAYOUT_QUADS):
         img, steps, _ = gpu_render(V, cameras["bonsai_1x1"], vol, 64, 64, dt=0.5, layout=lay)
         assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
     # a dense-core f16 volume exercises the early-out and the skip map's 0.1 threshold
@@ -311,8 +311,9 @@ def test_cameras_dims_and_dt(V, O):
                 assert np.abs(img - ref).max() <= TOL, (dims, lay, fl)
                 assert (steps == rsteps).all(), (dims, lay, fl)
                 assert s_samp == int(rsamp.sum())
-        img, steps, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=V.LAYOUT_BRICKED)  # 9^3 dense bricks
-        assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dims, "bricked")
+        for lay in (V.LAYOUT_BRICKED, V.LAYOUT_QUADS):  # 9^3 dense bricks; 2x2 (y,z) quads, one load per sample
+            img, steps, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay)
+            assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dims, lay)
 
 
 def test_compute_nearest_mode(V, O, golden, cameras):
@@ -548,13 +549,13 @@ def test_xor_generator_and_example(V, O, tmp_path):
 
 
 def test_large_volume_layouts_agree(V, O):
-    """Beyond the cache-resident sizes: a 640^3 u8 fog (262 M voxels) rendered through three independent
-    layouts/kernels (9^3 dense bricks, 8-B cells, dense linear) gives bitwise-identical frames and trip
-    counts, and a tile of it matches the CPU oracle."""
+    """Beyond the cache-resident sizes: a 640^3 u8 fog (262 M voxels) rendered through four independent
+    layouts/kernels (9^3 dense bricks, 2x2 quads, 8-B cells, dense linear) gives bitwise-identical frames and
+    trip counts, and a tile of it matches the CPU oracle."""
     n, W, H = 640, 960, 540
     cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
     imgs, steps = {}, {}
-    for name, lay in (("b9", V.LAYOUT_BRICKED), ("p8", V.LAYOUT_PACKED), ("lin", V.LAYOUT_LINEAR)):
+    for name, lay in (("b9", V.LAYOUT_BRICKED), ("q", V.LAYOUT_QUADS), ("p8", V.LAYOUT_PACKED), ("lin", V.LAYOUT_LINEAR)):
         ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
         try:
             V.VolumeTexture.generate_fog(ctx, (n, n, n), seed=0x5EED0005, layout=lay)
@@ -563,7 +564,7 @@ def test_large_volume_layouts_agree(V, O):
             imgs[name], steps[name] = ctx.read_backbuffer(), ctx.read_steps()
         finally:
             ctx.close()
-    for other in ("p8", "lin"):
+    for other in ("q", "p8", "lin"):
         assert (imgs["b9"].view(np.uint32) == imgs[other].view(np.uint32)).all(), other
         assert (steps["b9"] == steps[other]).all(), other
     assert steps["b9"].max() == 2 * n + 1  # dt_scale 0.5: <= 2n+1 iterations

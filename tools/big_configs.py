@@ -35,7 +35,7 @@ def run(name, dims, fmt, W, H, iters=5, seed=0x5EED0004, layout=V.LAYOUT_AUTO):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    lay = {"auto": V.LAYOUT_AUTO, "p8": V.LAYOUT_PACKED, "p16": V.LAYOUT_PACKED_PAIRS, "b9": V.LAYOUT_BRICKED}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
+    lay = {"auto": V.LAYOUT_AUTO, "p8": V.LAYOUT_PACKED, "p16": V.LAYOUT_PACKED_PAIRS, "b9": V.LAYOUT_BRICKED, "q": V.LAYOUT_QUADS}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
     if which in ("c4", "all"): run("C4 1024^3 f16 1920x1080", (1024,) * 3, V.FMT_R16_FLOAT, 1920, 1080, layout=lay)
     if which in ("c5small", "all"): run("C5-lite 1024^3 u8 3840x2160", (1024,) * 3, V.FMT_R8_UNORM, 3840, 2160, seed=0x5EED0005, layout=lay)
     if which in ("c5", "all"): run("C5 2048^3 u8 3840x2160", (2048,) * 3, V.FMT_R8_UNORM, 3840, 2160, iters=3, seed=0x5EED0005, layout=lay)

@@ -14,7 +14,7 @@ VK_OK = 0
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
 MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST, MODE_PROCEDURAL = 0, 1, 2
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED = 0, 1, 2, 3, 4
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, LAYOUT_QUADS = 0, 1, 2, 3, 4, 5
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 GEN_FOG, GEN_BONSAI_STANDIN = 0, 1

@@ -204,7 +204,7 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
             const double rec_bytes = ((double)((nx + 3) / 4)) * ((ny + 3) / 4) * ((nz + 3) / 4) * 64.0 * 16.0;
             layout = (rec_bytes <= (double)kPairOob && pair_lut_entries(nx, ny, nz) * 4u <= 16384u) ? VK_LAYOUT_PACKED : VK_LAYOUT_LINEAR;
         }
-        else if (cell_bytes > 4.0 * 1024 * 1024 * 1024) layout = VK_LAYOUT_BRICKED;
+        else if (cell_bytes > 4.0 * 1024 * 1024 * 1024) layout = VK_LAYOUT_BRICKED;  // (quads: faster only while rays are denser than voxels, see DESIGN)
         else layout = format == VK_FMT_R8_UNORM ? VK_LAYOUT_PACKED_PAIRS : VK_LAYOUT_PACKED;
     }
     if (format == VK_FMT_RGBA16F_PAIR && layout != VK_LAYOUT_LINEAR && layout != VK_LAYOUT_PACKED)
@@ -255,6 +255,29 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         drop_src();
         if (le != hipSuccess || se != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("record re-layout: ") + hipGetErrorString(le != hipSuccess ? le : se));
         ctx->vdesc.max_off = (int64_t)(n_rec - 1) * 16;
+        return VK_OK;
+    }
+    if (layout == VK_LAYOUT_QUADS) {
+        // quad elements in 9x8x8 bricks: padded coordinate c = i + 1 in [0, n] -> (n >> 3) + 1 bricks per axis
+        const bool f16q = format == VK_FMT_R16_FLOAT;
+        ctx->nbx = (nx >> 3) + 1; ctx->nby = (ny >> 3) + 1; ctx->nbz = (nz >> 3) + 1;
+        const uint64_t n_bricksq = (uint64_t)ctx->nbx * ctx->nby * ctx->nbz;
+        const uint64_t n_elems = n_bricksq * 576u;
+        const size_t ebytes = f16q ? 8 : 4;
+        if (n_bricksq >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large");
+        if (hipMalloc(&ctx->vol, n_elems * ebytes + 16) != hipSuccess) {  // + slack: a sample reads two elements
+            if (own_src) (void)hipFree(const_cast<void *>(d_src));
+            return fail(ctx, VK_ERR_OOM, "quad layout allocation failed (4.5x the dense bytes): use VK_LAYOUT_BRICKED");
+        }
+        ctx->vol_bytes = n_elems * ebytes;
+        ctx->vol_kind = f16q ? VOL_QF16 : VOL_Q8;
+        const uint32_t blocksq = (uint32_t)std::min<uint64_t>((n_elems + 255) / 256, 1ull << 22);  // grid-stride kernel
+        if (f16q) hipLaunchKernelGGL(pack_quads_kernel<true>, dim3(blocksq), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_elems);
+        else hipLaunchKernelGGL(pack_quads_kernel<false>, dim3(blocksq), dim3(256), 0, ctx->stream, d_src, ctx->vol, nx, ny, nz, ctx->nbx, ctx->nby, n_elems);
+        hipError_t leq = hipGetLastError();
+        hipError_t seq = hipStreamSynchronize(ctx->stream);
+        if (own_src) (void)hipFree(const_cast<void *>(d_src));
+        if (leq != hipSuccess || seq != hipSuccess) return fail(ctx, VK_ERR_HIP, std::string("quad re-layout: ") + hipGetErrorString(leq != hipSuccess ? leq : seq));
         return VK_OK;
     }
     if (layout == VK_LAYOUT_BRICKED) {
@@ -381,7 +404,7 @@ static int check_volume_args(vk_ctx *ctx, const void *p, const void *p2, uint32_
         return fail(ctx, VK_ERR_INVALID, "volume dims must be in [1, 8192]");
     if (format < VK_FMT_R8_UNORM || format > VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_INVALID, "unknown volume format");
     if (format == VK_FMT_RGBA16F_PAIR && !p2) return fail(ctx, VK_ERR_INVALID, "RGBA16F_PAIR needs the normals volume");
-    if (layout < VK_LAYOUT_AUTO || layout > VK_LAYOUT_BRICKED) return fail(ctx, VK_ERR_INVALID, "unknown layout");
+    if (layout < VK_LAYOUT_AUTO || layout > VK_LAYOUT_QUADS) return fail(ctx, VK_ERR_INVALID, "unknown layout");
     return VK_OK;
 }
 
@@ -834,6 +857,8 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
             case VOL_PF16: launch_packed<VOL_PF16>(ctx, L, V, grid, count, skip, safe); break;
             case VOL_B9U8: launch_naive<VOL_B9U8, false, true>(ctx, L, V, grid, count); break;
             case VOL_B9F16: launch_naive<VOL_B9F16, false, true>(ctx, L, V, grid, count); break;
+            case VOL_Q8: launch_naive<VOL_Q8, false, true>(ctx, L, V, grid, count); break;
+            case VOL_QF16: launch_naive<VOL_QF16, false, true>(ctx, L, V, grid, count); break;
             case VOL_LINEAR_F16: launch_naive<VOL_LINEAR_F16, false, true>(ctx, L, V, grid, count); break;
             default: launch_naive<VOL_LINEAR_U8, false, true>(ctx, L, V, grid, count); break;
         }

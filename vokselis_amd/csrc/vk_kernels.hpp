@@ -37,9 +37,15 @@ constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
 // voxels, clamp-to-edge baked in): brick b holds voxels [8b-1, 8b+7] per axis, so the 8 taps of any
 // sample come from ONE brick at fixed local offsets (+1, +9, +81).  1.42x the dense bytes instead
 // of 8-16x: the layout for volumes far larger than the caches.
+// Q8 / QF16 ("quads"): every stored element holds the 2x2 (y, z) neighbourhood of a voxel --
+// [v(x,y,z), v(x,y+1,z), v(x,y,z+1), v(x,y+1,z+1)], clamp-to-edge baked in -- so the 8 taps of a sample are
+// TWO CONSECUTIVE elements (x and x+1): one 8-byte (u8) or 16-byte (f16) load instead of the four scattered
+// x-pair loads of the 9^3 bricks.  Elements live in 9x8x8 bricks (x carries a one-element apron so the pair
+// never straddles a brick).  4.5x the dense bytes: for volumes far larger than the caches, where the
+// four-load layouts are bound by the texture-address path rather than by HBM.
 // PAIRB: the two rgba16f volumes of the compute mode interleaved as 16-byte (density, normals) records in
 // 4^3 bricks: one nearest-neighbour step is ONE aligned 16-byte load.
-enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6, VOL_PAIRB = 7 };
+enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6, VOL_PAIRB = 7, VOL_Q8 = 8, VOL_QF16 = 9 };
 enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 
 struct VolumeDesc {
@@ -677,6 +683,80 @@ __device__ __forceinline__ void march_b9_stream(const VolumeDesc &V, RayState &r
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
+// The quad layouts: one load per sample (two consecutive elements), software-pipelined like the others.
+template <int VOL, bool COUNT>
+__device__ __forceinline__ void march_quads_stream(const VolumeDesc &V, RayState &r, Census &cs) {
+    static_assert(VOL == VOL_Q8 || VOL == VOL_QF16, "quad layouts");
+    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+    const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
+    if (!(t < t1 && A < 0.95f)) return;
+    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // elements are 4 / 8 bytes: the pair is under-aligned
+    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    struct Taps { uint32_t a, b, c, d; };  // u8: a = element(x), b = element(x+1); f16: (a, b) = element(x), (c, d) = element(x+1)
+    auto request = [&](float ux, float uy, float uz) -> Taps {
+        const int cx = med3_i32(cvt_floor_i32(ux), -1, mx) + 1, cy = med3_i32(cvt_floor_i32(uy), -1, my) + 1, cz = med3_i32(cvt_floor_i32(uz), -1, mz) + 1;
+        const uint32_t brick = (uint32_t)(((cz >> 3) * (int)V.nby + (cy >> 3)) * (int)V.nbx + (cx >> 3));
+        const uint32_t local = (uint32_t)(((cz & 7) * 8 + (cy & 7)) * 9 + (cx & 7));
+        const uint64_t e = (uint64_t)brick * 576u + local;
+        Taps q;
+        if (VOL == VOL_Q8) {
+            const u32x2_a4 v = *reinterpret_cast<const u32x2_a4 *>(reinterpret_cast<const uint32_t *>(V.data) + e);
+            q.a = v.x; q.b = v.y; q.c = 0; q.d = 0;
+        } else {
+            const u32x4_a8 v = *reinterpret_cast<const u32x4_a8 *>(reinterpret_cast<const uint2 *>(V.data) + e);
+            q.a = v.x; q.b = v.y; q.c = v.z; q.d = v.w;
+        }
+        return q;
+    };
+    float fx, fy, fz;
+    Taps c0, c1;
+    {
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        c0 = request(ux, uy, uz);
+    }
+    auto trip = [&](const Taps &cur, Taps &nxt) -> bool {
+        if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; if (wave_leader()) { cs.w_outer++; cs.w_sample++; } }
+        px = px + sx; py = py + sy; pz = pz + sz;  // :118
+        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
+        nxt = request(ux, uy, uz);
+        float tp[8];  // tap index dx + 2*dy + 4*dz
+        if (VOL == VOL_Q8) {
+            tp[0] = (float)(cur.a & 0xffu); tp[2] = (float)((cur.a >> 8) & 0xffu); tp[4] = (float)((cur.a >> 16) & 0xffu); tp[6] = (float)(cur.a >> 24);
+            tp[1] = (float)(cur.b & 0xffu); tp[3] = (float)((cur.b >> 8) & 0xffu); tp[5] = (float)((cur.b >> 16) & 0xffu); tp[7] = (float)(cur.b >> 24);
+        } else {
+            tp[0] = h2f(cur.a & 0xffffu); tp[2] = h2f(cur.a >> 16); tp[4] = h2f(cur.b & 0xffffu); tp[6] = h2f(cur.b >> 16);
+            tp[1] = h2f(cur.c & 0xffffu); tp[3] = h2f(cur.c >> 16); tp[5] = h2f(cur.d & 0xffffu); tp[7] = h2f(cur.d >> 16);
+        }
+        const float c00 = fmaf(fx, tp[1] - tp[0], tp[0]), c10 = fmaf(fx, tp[3] - tp[2], tp[2]);
+        const float c01 = fmaf(fx, tp[5] - tp[4], tp[4]), c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
+        const float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
+        float v = fmaf(fz, l1 - l0, l0);
+        if (VOL == VOL_Q8) v = v * (1.0f / 255.0f);
+        const float a = transfer_alpha(v);
+        constexpr double kk = 6.28318 / 6.283185307179586476925;
+        constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+        constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+        const float cr = __builtin_amdgcn_cosf(a * pc0);
+        const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+        const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+        const float w = (1.0f - A) * a;  // :112-114
+        Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
+        A = A + w;
+        t = t + dt;
+        fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
+        return t < t1 && A < 0.95f;
+    };
+    for (;;) {
+        if (!trip(c0, c1)) break;
+        if (!trip(c1, c0)) break;
+    }
+    asm volatile("" ::"v"(c0.a), "v"(c0.b), "v"(c0.c), "v"(c0.d), "v"(c1.a), "v"(c1.b), "v"(c1.c), "v"(c1.d));
+    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+}
+
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
@@ -737,6 +817,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.out = (uint32_t)pm.out_index;
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);
+        else if constexpr (VOL == VOL_Q8 || VOL == VOL_QF16) march_quads_stream<VOL, COUNT>(V, r, cs);
         else march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
         A = r.A; Gr = r.Gr; Gg = r.Gg; Gb = r.Gb;
         Cr = linear_to_srgb(fmaf(0.5f, Gr, 0.5f * A));  // :121-123
@@ -1075,6 +1156,36 @@ __global__ __launch_bounds__(256) void pack_bricks9_kernel(const void *__restric
         size_t idx = (size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)z);
         if (F16) reinterpret_cast<uint16_t *>(dst)[id] = reinterpret_cast<const uint16_t *>(src)[idx];
         else reinterpret_cast<uint8_t *>(dst)[id] = reinterpret_cast<const uint8_t *>(src)[idx];
+    }
+}
+
+// Dense voxels -> quad elements in 9x8x8 bricks.  Padded coordinate c = i + 1 (i = low-corner voxel of a
+// footprint, i in [-1, n-1]) maps to voxel clamp(c - 1); brick (cx>>3, cy>>3, cz>>3), local (cx&7 .. with the
+// x apron lx = 8 repeating the next brick's lx = 0).  One thread per element.
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_quads_kernel(const void *__restrict__ src, void *__restrict__ dst, uint32_t nx, uint32_t ny,
+                                                         uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_elems) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_elems; id += stride) {
+        const uint64_t brick = id / 576u;
+        const uint32_t l = (uint32_t)(id - brick * 576u);
+        const uint32_t lz = l / 72u, ly = (l - lz * 72u) / 9u, lx = l - lz * 72u - ly * 9u;
+        const uint32_t bx = (uint32_t)(brick % nbx);
+        const uint64_t rest = brick / nbx;
+        const uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        const int cx = (int)(bx * 8 + lx), cy = (int)(by * 8 + ly), cz = (int)(bz * 8 + lz);
+        const int x = clampi(cx - 1, 0, (int)nx - 1);
+        const int y0 = clampi(cy - 1, 0, (int)ny - 1), y1 = clampi(cy, 0, (int)ny - 1);
+        const int z0 = clampi(cz - 1, 0, (int)nz - 1), z1 = clampi(cz, 0, (int)nz - 1);
+        const size_t sy_ = nx, sz_ = (size_t)nx * ny;
+        const size_t i00 = x + y0 * sy_ + z0 * sz_, i10 = x + y1 * sy_ + z0 * sz_, i01 = x + y0 * sy_ + z1 * sz_, i11 = x + y1 * sy_ + z1 * sz_;
+        if (F16) {
+            const uint16_t *v = reinterpret_cast<const uint16_t *>(src);
+            reinterpret_cast<uint2 *>(dst)[id] = make_uint2((uint32_t)v[i00] | ((uint32_t)v[i10] << 16), (uint32_t)v[i01] | ((uint32_t)v[i11] << 16));
+        } else {
+            const uint8_t *v = reinterpret_cast<const uint8_t *>(src);
+            reinterpret_cast<uint32_t *>(dst)[id] = (uint32_t)v[i00] | ((uint32_t)v[i10] << 8) | ((uint32_t)v[i01] << 16) | ((uint32_t)v[i11] << 24);
+        }
     }
 }
 
