@@ -225,7 +225,7 @@ def main():
                                 "bonsai camera (1,.5,1,(.5,.5,.5)), NAIVE_TRILINEAR, dt_scale 0.5 (<=513 steps/ray), rgba16f out",
                     "layout": {"pairs": "4^3-bricked cells, 4 (tap,delta) f16 pairs / 16 B", "packed": "4^3-bricked cells, 8 u8 taps / 8 B", "bricked": "dense 9^3 bricks, 8 scalar taps"}[args.layout],
                     "skip": not args.no_skip,
-                    "partition": "single launch" if world == 1 else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0, {args.gather_batch} frames per gather call, {args.frames_in_flight} frames in flight per rank",
+                    "partition": "single launch" if not use_dist else f"{TILE}x{TILE} tiles interleaved over {world} ranks + RCCL gather to rank 0, {args.gather_batch} frames per gather call, {args.frames_in_flight} frames in flight per rank",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
                 },
                 "roofline": {
