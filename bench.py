@@ -266,6 +266,32 @@ def main():
                     gb = (ss * B_STEP + W * H * B_RAY) / (ms * 1e-3) / 1e9
                     extras[f"{name}_{mode}"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+            # C2 again with several frames in flight (one stream each, as the N > 1 driver does per rank): frame
+            # THROUGHPUT when consecutive frames overlap, not the duration of one launch (that is `value` above)
+            try:
+                ctx_c2 = ctx
+                V.VolumeTexture.generate_standin(ctx_c2, (N_VOL,) * 3, layout=layout)
+                ctx_c2.sync()
+                fif = max(2, args.frames_in_flight)
+                slots1 = V.partition_slots(W, H, TILE, 1)
+                bufs = [torch.zeros((slots1, TILE, TILE, 4), dtype=torch.float16, device="cuda") for _ in range(fif)]
+                side = [torch.cuda.Stream() for _ in range(fif)]
+                for st in side:
+                    st.wait_stream(torch.cuda.current_stream())
+                pf = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
+                for k in range(2 * fif):
+                    pf.record_partition(ctx_c2, TILE, 0, 1, bufs[k % fif].data_ptr(), stream=side[k % fif].cuda_stream)
+                torch.cuda.synchronize()
+                kf = 200
+                t0f = time.perf_counter()
+                for k in range(kf):
+                    pf.record_partition(ctx_c2, TILE, 0, 1, bufs[k % fif].data_ptr(), stream=side[k % fif].cuda_stream)
+                torch.cuda.synchronize()
+                msf = (time.perf_counter() - t0f) / kf * 1e3
+                extras[f"standin_skip_{fif}_frames_in_flight"] = {"ms_per_frame": msf, "Mray_steps_per_s": s_ref / msf / 1e3,
+                                                                 "note": "tiles into compact buffers (vk_render_partition_on), no un-tile; throughput, not launch duration"}
+            except Exception as e:
+                extras["standin_skip_frames_in_flight"] = {"error": str(e)}
             # the compute twin (raycast_compute.wgsl `single`) on the xor example's own configuration:
             # 256^3 rgba16f pair generated on the device, 1280x720, xor camera, dt = 0.01; 16 B per step
             try:
