@@ -389,10 +389,6 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
     V.kz = (64 * bxyn - 64) * cb;
     V.c0 = (64 * bxyn + 64 * bxn + 64) * cb;
     V.max_off = (int64_t)(n_cells - 1) * cb;
-    V.ci0 = (int32_t)std::min<int64_t>(64 * bxyn + 64 * bxn + 64, INT32_MAX);
-    V.ciy = (int32_t)std::min<int64_t>(64 * bxn - 16, (1 << 23) - 1);
-    V.ciz = (int32_t)std::min<int64_t>(64 * bxyn - 64, (1 << 23) - 1);
-    V.max_idx = (uint32_t)std::min<uint64_t>(n_cells - 1, 0xffffffffu);
     return VK_OK;
 }
 

@@ -61,10 +61,6 @@ struct VolumeDesc {
     int64_t kz, c0, max_off;
     int32_t kx, ky;
     uint32_t sh_x, sh_y, sh_z;
-    // the same in cell units (SAFE=false path): idx = ci0 + (ix + 60*bx) + (4*iy + ciy*by) + (16*iz + ciz*bz)
-    // (an inline-asm v_mad_i32_i24 chain was 3-5 % slower than what hipcc schedules for this expression)
-    int32_t ci0, ciy, ciz;
-    uint32_t max_idx;
 };
 
 struct LaunchDesc {
@@ -223,11 +219,11 @@ __device__ __forceinline__ float trilerp(const float t[8], float fx, float fy, f
 // The loop is VALU-issue bound on gfx950 (~4.4 cycles per wave64 VALU instruction at 8 waves/SIMD,
 // tools/ubench/valu_rate.hip), so the kernel is written for instruction count:
 //  * v_cvt_flr_i32_f32 + v_fract_f32 give the cell index and the lerp weight in 2 ops per axis;
-//  * brick addressing is three multiply-adds: with b = i >> 2, the cell index
-//    ((Bz*nby + By)*nbx + Bx)*64 + wz*16 + wy*4 + wx  (B = b+1, w = i - 4b) is affine in (i, b);
+//  * the cell index ((Bz*nby + By)*nbx + Bx)*64 + wz*16 + wy*4 + wx  (B = (i>>2)+1, w = i&3) splits per axis, so the
+//    fast path (SAFE=false) reads it from three small LDS tables: 4 VALU + 3 ds_read_b32 instead of 14 VALU;
 //  * P16 cells hold (tap, delta) f16 pairs so an x-lerp is one v_fma_mix_f32, no unpack;
-//  * SAFE=false drops the per-axis clamps and uses 32-bit offsets from an SGPR base when the
-//    host has proved both are safe (vk_api.hip: render_common).
+//  * SAFE=false also drops the per-axis clamps and reads cells through a bounds-checked 32-bit-offset buffer
+//    resource when the host has proved both are safe (vk_api.hip: render_common); SAFE=true keeps the closed form.
 __device__ __forceinline__ int cvt_floor_i32(float u) {
     int i;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
