@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather path even at N = 1 (self-test)")
-    ap.add_argument("--frames-in-flight", type=int, default=4, help="N > 1: frames marched concurrently per rank (own stream each)")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="N > 1: frames marched concurrently per rank (own stream each)")
     ap.add_argument("--gather-batch", type=int, default=8, help="N > 1: frames moved per gather call (a collective call costs ~100 us of host time)")
     return ap.parse_args()
 
