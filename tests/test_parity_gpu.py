@@ -246,6 +246,54 @@ def test_tile_parallel_renderer_over_rccl_world1(V, O):
             dist.destroy_process_group()
 
 
+def test_tile_parallel_renderer_frames_in_flight_stress(V, O):
+    """The bench configuration of the N > 1 driver (8 frames per gather, 8 frames in flight) on the C2 frame, as a
+    world of one: every delivered frame is checked, in order, against the single-launch frame of its own dt."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from vokselis_amd.dist import TileParallelRenderer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    W, H = 1920, 1080
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+    ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    ref_ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    try:
+        dts = (0.5, 0.8, 1.3)
+        want = []
+        for c in (ctx, ref_ctx):
+            V.VolumeTexture.generate_standin(c, (256,) * 3); c.update()
+        for dt in dts:
+            V.RaycastPipeline(dt_scale=dt).record(ref_ctx)
+            want.append(ref_ctx.read_backbuffer().view(np.uint16).copy())
+        bad = []
+
+        def check(k):
+            got = ctx.read_backbuffer().view(np.uint16)  # synchronises the main stream: frame k is complete
+            if not (got == want[k % 3]).all():
+                bad.append(k)
+
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pipe = V.RaycastPipeline(dt_scale=dts[0])
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=8, frames_in_flight=8, on_frame=check)
+            for k in range(29):  # three full batches + a partial one
+                pipe.dt_scale = dts[k % 3]
+                tpr.submit(k)
+            tpr.flush()
+        assert tpr._delivered == 29 and not bad, bad
+    finally:
+        ctx.close(); ref_ctx.close()
+        if created:
+            dist.destroy_process_group()
+
+
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)

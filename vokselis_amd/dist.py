@@ -102,7 +102,7 @@ class TileParallelRenderer:
     """March + gather + un-tile for one frame stream on this rank's GPU."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, root: int = 0, group=None, batch: int = 1,
-                 frames_in_flight: int = 1):
+                 frames_in_flight: int = 1, on_frame=None):
         """`batch` frames travel per gather call; up to `frames_in_flight` of them are marched concurrently,
         each on its own stream into its own slice of the batch buffer.  A rank's share of a small frame is a
         few hundred waves whose length is set by the slowest one; overlapping consecutive frames is what keeps
@@ -131,6 +131,8 @@ class TileParallelRenderer:
         self._active, self._active_key = None, None
         self._n = None        # active slots of the batch being filled
         self._set, self._filled = 0, 0
+        self.on_frame = on_frame  # root only: called as on_frame(k) right after frame k (in submit order) was un-tiled
+        self._submitted, self._delivered = 0, 0
         self._fif = max(1, min(int(frames_in_flight), self.fg.batch))
         self._main = torch.cuda.current_stream()
         self._side, self._done, self._free = [], [], [None, None]
@@ -200,11 +202,16 @@ class TileParallelRenderer:
                 frame_bytes = n * fg.ts * fg.ts * 4 * self._esize
                 for b in range(count):  # every frame of the batch materialises in the root's backbuffer, in order
                     N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, base + b * frame_bytes, fg.ts, fg.world, fg.batch * n))
+                    if self.on_frame is not None:
+                        self.on_frame(self._delivered + b)
             else:
                 # no tile touches the cube: the un-tile only clears (it reads no slot), once per frame
                 dummy = fg.buffers(1)[1][0].data_ptr()
-                for _ in range(count):
+                for b in range(count):
                     N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, dummy, fg.ts, fg.world, fg.batch))
+                    if self.on_frame is not None:
+                        self.on_frame(self._delivered + b)
+        self._delivered += count
         self._pending = None
 
     def flush(self):
