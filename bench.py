@@ -241,6 +241,20 @@ def main():
                 },
                 "device": info["device_name"], "volume_setup_s": t_volume,
             }
+            if not use_dist:
+                # distribution of single-launch durations (median, p10 / p90): one event pair per launch
+                # on the launch stream, 100 launches, outside the timed region
+                try:
+                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+                    for a, b in evs:
+                        a.record(stream)
+                        pipe.record(ctx)
+                        b.record(stream)
+                    torch.cuda.synchronize()
+                    d = sorted(a.elapsed_time(b) for a, b in evs)
+                    out["roofline"].update({"launch_ms_p10": d[10], "launch_ms_p50": d[50], "launch_ms_p90": d[90]})
+                except Exception:
+                    pass
             prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(prof) and world == 1 and not args.no_skip and args.layout == "pairs":
                 try:
