@@ -594,6 +594,16 @@ def test_xor_generator_and_example(V, O, tmp_path):
         got = np.frombuffer(data, np.uint8).reshape(H, W, 3).astype(np.int32)
         d = np.abs(got - want)
         assert d.max() <= 2 and (d == 0).mean() > 0.99, (mode, d.max(), (d == 0).mean())
+    # the C3 surrogate through the compiled host: no volume, un.time pinned, presented like any other frame
+    refp, _ = O.render_procedural(cam, W, H, time=0.5)
+    wantp = O.present(O.rgba32f_to_rgba16f(refp).view(np.float16).astype(np.float32), W, H)[..., :3].astype(np.int32)
+    ppm = tmp_path / "xor_procedural.ppm"
+    r = subprocess.run([exe, "--frames", "2", "--size", f"{W}x{H}", "--mode", "procedural", "--time", "0.5", "--ppm", str(ppm)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    gotp = np.frombuffer(ppm.read_bytes().split(b"\n255\n", 1)[1], np.uint8).reshape(H, W, 3).astype(np.int32)
+    dp = np.abs(gotp - wantp)
+    assert dp.max() <= 2 and (dp == 0).mean() > 0.99, (dp.max(), (dp == 0).mean())
 
 
 def test_large_volume_layouts_agree(V, O):

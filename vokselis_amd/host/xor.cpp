@@ -1,7 +1,8 @@
 // xor.cpp -- headless counterpart of `cargo run --example xor` (examples/xor/main.rs): the procedural
 // volume (shaders/xor.wgsl) marched by the compute raycast (shaders/raycast_compute.wgsl), either as
 // one `single` dispatch or as the reference's loop of 256-pixel `tile` dispatches with offsets.
-//   xor [--frames N] [--size WxH] [--mode single|tile] [--volume N] [--ppm out.ppm]
+//   xor [--frames N] [--size WxH] [--mode single|tile|procedural] [--volume N] [--time T] [--ppm out.ppm]
+// `procedural` marches shaders/xor.wgsl's density function itself, no volume; --time pins un.time.
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -10,7 +11,9 @@
 
 using namespace vokselis;
 
-enum class Mode { SinglePass, Tile };  // examples/xor/main.rs:14-18 (F1 toggles it there)
+enum class Mode { SinglePass, Tile, Procedural };  // examples/xor/main.rs:14-18 (F1 toggles the first two there)
+static bool g_pin_time = false;
+static float g_time = 0.f;
 static Mode g_mode = Mode::SinglePass;
 static uint32_t g_vol = 256;
 static const uint32_t TILE_SIZE = 256;  // examples/xor/main.rs:12
@@ -21,6 +24,10 @@ struct Xor : Demo {
     std::vector<std::pair<int32_t, int32_t>> offsets;
     static std::unique_ptr<Xor> init(Context &ctx) {  // examples/xor/main.rs:41-162
         auto self = std::make_unique<Xor>();
+        if (g_mode == Mode::Procedural) {
+            self->raycast = RaycastPipeline{VK_MODE_PROCEDURAL, 1.0f, 0};  // no volume at all
+            return self;
+        }
         self->xor_texture = std::make_unique<VolumeTexture>(VolumeTexture::generate_xor(ctx, g_vol, g_vol, g_vol, 0.f));
         self->raycast = RaycastPipeline{VK_MODE_COMPUTE_NEAREST, 1.0f, 0};
         const HdrBackBuffer &bb = ctx.render_backbuffer;
@@ -28,8 +35,14 @@ struct Xor : Demo {
             for (uint32_t x = 0; x < bb.width / TILE_SIZE + 1; x++) self->offsets.push_back({(int32_t)(x * TILE_SIZE), (int32_t)(y * TILE_SIZE)});
         return self;
     }
+    void update(Context &ctx) override {
+        if (g_pin_time) {  // Context::update has just uploaded the clock; a pinned un.time replaces it
+            ctx.global_uniform.time = g_time;
+            check(ctx.handle(), vk_set_uniform(ctx.handle(), &ctx.global_uniform));
+        }
+    }
     void render(Context &ctx) override {  // examples/xor/main.rs:210-262
-        if (g_mode == Mode::SinglePass) raycast.record(ctx);
+        if (g_mode != Mode::Tile) raycast.record(ctx);
         else for (auto &o : offsets) raycast.record_tile(ctx, o.first, o.second, TILE_SIZE, TILE_SIZE);
     }
 };
@@ -42,7 +55,8 @@ int main(int argc, char **argv) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
         if (a == "--frames") frames = (uint32_t)std::atoi(next());
         else if (a == "--size") { if (std::sscanf(next(), "%ux%u", &w, &h) != 2) { std::fprintf(stderr, "--size WxH\n"); return 2; } }
-        else if (a == "--mode") { std::string m = next(); g_mode = m == "tile" ? Mode::Tile : Mode::SinglePass; }
+        else if (a == "--mode") { std::string m = next(); g_mode = m == "tile" ? Mode::Tile : (m == "procedural" ? Mode::Procedural : Mode::SinglePass); }
+        else if (a == "--time") { g_time = (float)std::atof(next()); g_pin_time = true; }
         else if (a == "--volume") g_vol = (uint32_t)std::atoi(next());
         else if (a == "--ppm") ppm = next();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -54,7 +68,7 @@ int main(int argc, char **argv) {
         std::printf("%s\n", ctx.get_info().c_str());
         double ms = 0;
         auto demo = run_headless<Xor>(ctx, frames, &ms);
-        std::printf("Avg frame time %.4fms over %u frames (%s)\n", ms, frames, g_mode == Mode::Tile ? "Tile" : "SinglePass");
+        std::printf("Avg frame time %.4fms over %u frames (%s)\n", ms, frames, g_mode == Mode::Tile ? "Tile" : (g_mode == Mode::Procedural ? "Procedural" : "SinglePass"));
         auto shot = ctx.capture_frame();
         uint64_t sum = 0;
         for (uint8_t b : shot.first) sum += b;
