@@ -54,4 +54,22 @@ rest_list = list(rest); out = []
 for x in inter:
     out.append(x if x is not None else rest_list.pop())
 apply(np.concatenate([np.array(out), np.array(rest_list, dtype=int)]), "true-work LPT over XCDs")
+# proxy check: outer trips only (what a production kernel can count for free on the scalar unit)
+def lpt(cost_vec, label):
+    srt2 = act[np.argsort(-cost_vec[:n_active], kind="stable")]
+    rounds, rem = n_active // 8, n_active % 8
+    bins2 = [[] for _ in range(8)]; load2 = np.zeros(8)
+    for p_ in srt2:
+        cand = [b for b in range(8) if len(bins2[b]) < rounds + (1 if b < rem else 0)]
+        b = min(cand, key=lambda j: load2[j]); bins2[b].append(p_); load2[b] += cost_vec[p_]
+    out2 = []
+    for r_ in range(rounds + 1):
+        for b in range(8):
+            if r_ < len(bins2[b]): out2.append(bins2[b][r_])
+    true_load = np.array([tile_cost[bins2[b]].sum() for b in range(8)])
+    print(label, "true XCD loads / mean:", (true_load / true_load.mean()).round(3))
+    apply(np.concatenate([np.array(out2), rest]), label)
+lpt(tile_cost, "LPT no holes, true work")
+lpt((wo.reshape(-1, 64) + 4 * (wo.reshape(-1, 64) > 0)).sum(1), "LPT no holes, outer trips only")
+lpt((wo.reshape(-1, 64) * 28 + wi.reshape(-1, 64) * 9).sum(1), "LPT no holes, trips + walk")
 ctx.close()
