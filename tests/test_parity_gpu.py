@@ -246,6 +246,98 @@ def test_tile_parallel_renderer_over_rccl_world1(V, O):
             dist.destroy_process_group()
 
 
+def _tpr_two_ranks_worker(rank, world, port, q):
+    """One of two processes sharing cuda:0: the production TileParallelRenderer with rank/world = (rank, 2); only the
+    wire is replaced (gloo through host memory -- RCCL refuses two ranks on one device)."""
+    import os
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import vokselis_amd as V
+    from vokselis_amd.dist import FrameGather, TileParallelRenderer
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class HostStagedGather(FrameGather):
+        def start(self, set_, n=None, count=None):
+            n = self.slots if n is None else min(int(n), self.slots)
+            count = self.batch if count is None else count
+            compact, gathered = self.buffers(n)
+            torch.cuda.current_stream().synchronize()          # the frames of this batch are marched
+            send = compact[set_][:count].cpu()
+            recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.root else None
+            self.dist.gather(send, gather_list=recv, dst=self.root, group=self.group)
+            if self.rank == self.root:
+                for r in range(self.world):
+                    gathered[set_][r, :count].copy_(recv[r])
+
+            class Done:
+                def wait(self_inner):
+                    return True
+            return Done()
+
+    try:
+        W, H = 640, 360
+        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+        ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+        V.VolumeTexture.generate_standin(ctx, (128,) * 3); ctx.update()
+        dts = (0.5, 1.0, 0.7)
+        want = []
+        if rank == 0:
+            ref = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+            V.VolumeTexture.generate_standin(ref, (128,) * 3); ref.update()
+            for dt in dts:
+                V.RaycastPipeline(dt_scale=dt).record(ref)
+                want.append(ref.read_backbuffer().view(np.uint16).copy())
+            ref.close()
+        bad = []
+
+        def check(k):
+            got = ctx.read_backbuffer().view(np.uint16)
+            if not (got == want[k % 3]).all():
+                bad.append(k)
+
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pipe = V.RaycastPipeline(dt_scale=dts[0])
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=4, frames_in_flight=4, gather_cls=HostStagedGather,
+                                       on_frame=check if rank == 0 else None)
+            for k in range(11):  # two full batches + a partial one
+                pipe.dt_scale = dts[k % 3]
+                tpr.submit(k)
+            tpr.flush()
+        ctx.close()
+        q.put((rank, tpr._delivered, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_parallel_renderer_two_ranks_one_gpu(V, O):
+    """The N > 1 driver with two real ranks (two processes on this GPU): tiles dealt to both, batches of 4 frames, 4
+    frames in flight, every frame delivered on the root checked against the single-launch frame."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_tpr_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(300)
+        assert p_.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert got[0][0] == 0 and got[0][1] == 11 and got[0][2] == [], got
+    assert got[1][0] == 1 and got[1][1] == 11, got
+
+
 def test_tile_parallel_renderer_frames_in_flight_stress(V, O):
     """The bench configuration of the N > 1 driver (8 frames per gather, 8 frames in flight) on the C2 frame, as a
     world of one: every delivered frame is checked, in order, against the single-launch frame of its own dt."""

@@ -102,7 +102,7 @@ class TileParallelRenderer:
     """March + gather + un-tile for one frame stream on this rank's GPU."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, root: int = 0, group=None, batch: int = 1,
-                 frames_in_flight: int = 1, on_frame=None):
+                 frames_in_flight: int = 1, on_frame=None, gather_cls=None):
         """`batch` frames travel per gather call; up to `frames_in_flight` of them are marched concurrently,
         each on its own stream into its own slice of the batch buffer.  A rank's share of a small frame is a
         few hundred waves whose length is set by the slowest one; overlapping consecutive frames is what keeps
@@ -124,7 +124,9 @@ class TileParallelRenderer:
         bb = ctx.render_backbuffer
         dtype = torch.float32 if bb.format == N.OUT_RGBA32F else torch.float16
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.fg = FrameGather(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group, batch=batch)
+        # gather_cls: a FrameGather subclass (tests move the buffers over gloo through host memory, so that several
+        # ranks can share one GPU); the production class hands the device buffers to RCCL
+        self.fg = (gather_cls or FrameGather)(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group, batch=batch)
         assert self.fg.slots == partition_slots(bb.width, bb.height, tile_size, self.fg.world)
         self._esize = 4 if bb.format == N.OUT_RGBA32F else 2
         self._pending = None  # (set, n, count, work) of the batch whose un-tile is still owed
