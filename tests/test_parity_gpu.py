@@ -456,6 +456,39 @@ def test_cameras_dims_and_dt(V, O):
             assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dims, lay)
 
 
+def test_skip_fuzz_cameras_dims_dt(V, O):
+    """Seeded fuzz of the skip path: random volume dims, cameras (outside, inside, axis-aligned, grazing), image
+    sizes and dt_scale; skip == no-skip bitwise, trip counts and tap-fetching steps identical to the oracle."""
+    rng = np.random.default_rng(20261003)
+    cases = 0
+    for trial in range(24):
+        dims = tuple(int(x) for x in rng.integers(5, 72, 3))
+        W, H = int(rng.integers(24, 96)), int(rng.integers(24, 96))
+        kind = trial % 4
+        if kind == 0:    # ordinary orbit
+            cam_args = (float(rng.uniform(0.7, 2.5)), float(rng.uniform(-1.4, 1.4)), float(rng.uniform(0, 6.28)), (0.5, 0.5, 0.5), W / H)
+        elif kind == 1:  # eye inside the volume
+            cam_args = (float(rng.uniform(0.05, 0.4)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0, 6.28)),
+                        tuple(float(x) for x in rng.uniform(0.3, 0.7, 3)), W / H)
+        elif kind == 2:  # axis-aligned views: direction components that are exactly zero on the centre rays
+            cam_args = (1.5, 0.0, float(rng.integers(0, 4)) * 1.5707963, (0.5, 0.5, 0.5), 1.0)
+        else:            # grazing: looking along a face
+            cam_args = (1.2, float(rng.uniform(-0.05, 0.05)), float(rng.uniform(0, 6.28)), (0.5, float(rng.choice([0.02, 0.98])), 0.5), W / H)
+        dt = float(rng.choice([0.15, 0.5, 1.0, 1.7]))
+        vol = O.volume_standin_u8(dims, seed=int(rng.integers(1, 1 << 30))) if min(dims) >= 17 else rng.integers(0, 60, (dims[2], dims[1], dims[0])).astype(np.uint8)
+        cam = O.camera_blob(*cam_args)
+        ref, rsteps, rsamp = O.render(cam, vol, W, H, dt_scale=dt)
+        for lay in (V.LAYOUT_PACKED_PAIRS, V.LAYOUT_PACKED):
+            a, sa, (_, ma) = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay)
+            b, sb, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay, flags=V.RENDER_NO_SKIP)
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (trial, dims, cam_args, dt, lay)
+            assert (sa == rsteps).all() and (sb == rsteps).all(), (trial, dims, cam_args, dt, lay)
+            assert ma == int(rsamp.sum()), (trial, dims, cam_args, dt, lay)
+            assert np.abs(a - ref).max() <= TOL, (trial, dims, cam_args, dt, lay)
+            cases += 1
+    assert cases == 48
+
+
 def test_compute_nearest_mode(V, O, golden, cameras):
     """raycast_compute.wgsl `single` and `tile` (A10-A12) against the golden vectors."""
     g = golden["compute_128x72"]
