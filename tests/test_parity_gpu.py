@@ -487,6 +487,24 @@ def test_skip_fuzz_cameras_dims_dt(V, O):
             assert np.abs(a - ref).max() <= TOL, (trial, dims, cam_args, dt, lay)
             cases += 1
     assert cases == 48
+    # f16 volumes (threshold 0.1 for an empty cell): blobs in air
+    for trial in range(8):
+        dims = tuple(int(x) for x in rng.integers(9, 60, 3))
+        W, H = int(rng.integers(32, 80)), int(rng.integers(32, 80))
+        z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+        vol = np.full(x.shape, 0.02, np.float32)
+        for _ in range(4):
+            c = rng.uniform(0.2, 0.8, 3) * np.array(dims); rad = rng.uniform(2, 0.3 * min(dims))
+            d2 = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2
+            vol = np.maximum(vol, np.where(d2 < rad * rad, rng.uniform(0.15, 1.0), 0.0))
+        vol = vol.astype(np.float16)
+        cam = O.camera_blob(float(rng.uniform(0.3, 2.0)), float(rng.uniform(-1.2, 1.2)), float(rng.uniform(0, 6.28)), (0.5, 0.5, 0.5), W / H)
+        dt = float(rng.choice([0.3, 0.5, 1.0]))
+        ref, rsteps, rsamp = O.render(cam, vol, W, H, dt_scale=dt)
+        a, sa, (_, ma) = gpu_render(V, cam, vol, W, H, dt=dt, layout=V.LAYOUT_PACKED)
+        b, sb, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=V.LAYOUT_PACKED, flags=V.RENDER_NO_SKIP)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all() and (sa == rsteps).all() and (sb == rsteps).all(), (trial, dims, dt)
+        assert ma == int(rsamp.sum()) and np.abs(a - ref).max() <= TOL, (trial, dims, dt)
 
 
 def test_compute_nearest_mode(V, O, golden, cameras):
