@@ -261,6 +261,9 @@ def main():
                     pj = json.load(open(prof))
                     out["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = pj.get("source", "profiles/r01_pmc_traffic.json")
+                    # SURVEY 8(d), reported beside the judged figure: physical (PMC) and compulsory traffic rates
+                    out["roofline"]["physical_GBps"] = pj["hbm_bytes_per_launch"] / (ev_ms * 1e-3) / 1e9
+                    out["roofline"]["compulsory_GBps"] = (N_VOL ** 3 + n_px * B_RAY) / (ev_ms * 1e-3) / 1e9
                 except Exception:
                     pass
 
