@@ -161,7 +161,9 @@ int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *orde
 int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nranks, uint32_t *n_active_tiles,
                         uint32_t *n_active_slots);
 /* Root side: scatter the gathered [nranks][slot_stride][ts][ts] pixels into the backbuffer; tiles beyond
- * the active ones are cleared to (0,0,0,1). */
+ * the active ones are cleared to (0,0,0,1).  Uses the order of the LAST partition call on this context, so
+ * frames marched before a camera change are un-tiled as they were dealt: deliver them before the next
+ * partition call under the new camera (vokselis_amd/dist.py drains its pipeline at that point). */
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride);
 
 /* ---- present + screenshot ---------------------------------------- */

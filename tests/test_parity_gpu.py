@@ -224,22 +224,33 @@ def test_tile_parallel_renderer_over_rccl_world1(V, O):
           with torch.cuda.stream(torch.cuda.Stream()):  # the collective is ordered against torch's current stream
             for c in (ctx, ref_ctx):
                 c.camera.set_zoom(1.0); c.update()
+            expect, bad = [], []
+
+            def check(k):
+                if not (ctx.read_backbuffer().view(np.uint16) == expect[k]).all():
+                    bad.append(k)
+
             pipe = V.RaycastPipeline(dt_scale=1.0)
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=3, frames_in_flight=fif)
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=3, frames_in_flight=fif, on_frame=check)
             for k, dt in enumerate((1.0, 0.5, 0.25, 0.75)):   # one full batch + one frame
                 pipe.dt_scale = dt
+                expect.append(direct(dt))
                 tpr.submit(k)
             tpr.flush()
             assert (ctx.read_backbuffer().view(np.uint16) == direct(0.75)).all()
             pipe.dt_scale = 0.5
-            tpr.submit(4); tpr.submit(5)                      # partial batch
-            # camera change inside a batch: the active tile set changes size
+            expect += [direct(0.5), direct(0.5)]
+            tpr.submit(4); tpr.submit(5)                      # partial batch under the old camera
+            # camera change inside a batch: the tiles are re-dealt (other order, other active set); the two frames
+            # above must still be delivered as they were marched
             for c in (ctx, ref_ctx):
                 c.camera.set_zoom(2.5)
                 c.update()
+            expect.append(direct(0.5))
             tpr.submit(6)
             tpr.flush()
             assert (ctx.read_backbuffer().view(np.uint16) == direct(0.5)).all()
+            assert tpr._delivered == 7 and not bad, (fif, bad)
     finally:
         ctx.close(); ref_ctx.close()
         if created:

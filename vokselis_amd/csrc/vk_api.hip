@@ -940,13 +940,19 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
     if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "vk_untile: no camera (the tile order follows the camera)");
+    const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
     {
-        int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
-        if (orc) return orc;
+        // The un-tile follows the order the partitions were marched with: the tables of the LAST partition call,
+        // not those of a camera uploaded since (frames still in the pipeline when the camera moves are delivered
+        // as they were dealt).  Only a context that has never partitioned this frame shape derives them here.
+        const size_t n_tiles = (size_t)tiles_x * ((ctx->height + tile_size - 1) / tile_size);
+        if (!ctx->d_order_pos || ctx->order.size() != n_tiles) {
+            int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+            if (orc) return orc;
+        }
     }
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
     const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
     if (ctx->out_format == VK_OUT_RGBA16F)
         hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos, ctx->order_active);

@@ -155,11 +155,14 @@ class TileParallelRenderer:
             raise RuntimeError("TileParallelRenderer must be driven on the torch stream it was created on")
         key = (id(self.ctx), self.ctx.camera_epoch)
         if self._active_key != key:
+            # A new camera re-deals the tiles: frames marched under the old order must be gathered AND un-tiled
+            # before the library rebuilds its order tables (which the next call below does), so the pipeline is
+            # drained here.  A camera that moves every frame therefore runs one frame at a time.
+            if self._active_key is not None:
+                self.flush()
             self._active = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)[1]  # per uploaded camera; cached in the library too
             self._active_key = key
         n = self._active
-        if self._n is not None and n != self._n and self._filled:
-            self._launch_batch()  # the camera changed the active set: close the batch at its old size
         self._n = n
         if n > 0:
             compact, _ = fg.buffers(n)
