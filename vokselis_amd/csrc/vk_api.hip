@@ -54,8 +54,16 @@ struct vk_ctx {
     unsigned long long *trace = nullptr;
     size_t trace_blocks = 0;
     bool want_trace = false;
-    uint32_t *d_order = nullptr, *d_order_pos = nullptr;
-    size_t d_order_cap = 0;
+    // The device copies of (order, order_pos) live in a ring of kOrderRing slots fed from pinned staging: a new
+    // camera takes the next slot with one stream-ordered copy -- no host or device synchronisation -- while
+    // launches still in flight (other streams: frames in flight) keep reading the slots they were given.
+    uint32_t *d_order = nullptr, *d_order_pos = nullptr;  // the current slot
+    uint32_t *d_ring = nullptr, *h_ring = nullptr;
+    size_t d_order_cap = 0;      // entries per table in every slot
+    int ring_slot = -1;
+    hipEvent_t ring_ev[16] = {};     // slot uploaded
+    hipStream_t ring_stream[16] = {};
+    bool ring_done[16] = {};
 
     // present targets (next row N1/N2)
     uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
@@ -152,8 +160,9 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->rgba8) (void)hipFree(ctx->rgba8);
     if (ctx->bgra8) (void)hipFree(ctx->bgra8);
     if (ctx->trace) (void)hipFree(ctx->trace);
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
-    if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
+    if (ctx->d_ring) (void)hipFree(ctx->d_ring);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+    for (hipEvent_t e : ctx->ring_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -690,25 +699,44 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     ctx->order_active = n_active;
     ctx->order_pos.resize(n);
     for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
+    constexpr int kOrderRing = 16;
     if (ctx->d_order_cap < n) {
-        // other streams' launches (frames in flight) may still read the old tables
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        if (ctx->d_order) (void)hipFree(ctx->d_order);
-        if (ctx->d_order_pos) (void)hipFree(ctx->d_order_pos);
-        ctx->d_order = ctx->d_order_pos = nullptr;
-        ctx->d_order_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_order, n * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_order_pos, n * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipDeviceSynchronize());  // a larger frame shape: rebuild the ring (rare)
+        if (ctx->d_ring) (void)hipFree(ctx->d_ring);
+        if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+        ctx->d_ring = ctx->h_ring = nullptr; ctx->d_order = ctx->d_order_pos = nullptr;
+        ctx->d_order_cap = 0; ctx->ring_slot = -1;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
         ctx->d_order_cap = n;
     }
-    // Earlier launches may still read the old table.  On this context's stream the copies are ordered behind
-    // them; launches placed on other streams (vk_render_partition_on: frames in flight) are not, so a change
-    // of the order (new camera / region) first waits for the device -- once per camera, not per frame.
-    if (!ctx->order_key.empty()) HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host vectors may be rewritten by the next call
+    const size_t cap = ctx->d_order_cap;
+    const int slot = (ctx->ring_slot + 1) % kOrderRing;
+    // the slot's previous upload (kOrderRing cameras ago) has long completed; waiting on it also makes the pinned
+    // staging safe to rewrite.  Launches that still READ that old slot would have to be > kOrderRing - 1 cameras
+    // behind: the N > 1 driver drains at every camera change, single-stream use is stream-ordered.
+    if (ctx->ring_ev[slot]) HIP_TRY(ctx, hipEventSynchronize(ctx->ring_ev[slot]));
+    else HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ring_ev[slot], hipEventDisableTiming));
+    uint32_t *hs = ctx->h_ring + (size_t)slot * 2 * cap, *ds = ctx->d_ring + (size_t)slot * 2 * cap;
+    std::memcpy(hs, ctx->order.data(), n * sizeof(uint32_t));
+    std::memcpy(hs + cap, ctx->order_pos.data(), n * sizeof(uint32_t));
+    HIP_TRY(ctx, hipMemcpyAsync(ds, hs, (cap + n) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ring_ev[slot], ctx->stream));
+    ctx->ring_stream[slot] = ctx->stream;
+    ctx->ring_done[slot] = false;
+    ctx->ring_slot = slot;
+    ctx->d_order = ds;
+    ctx->d_order_pos = ds + cap;
     ctx->order_key = key;
+    return VK_OK;
+}
+
+// A launch on a stream other than the one that uploaded the current order slot waits for that upload.
+static int order_wait(vk_ctx *ctx) {
+    const int s = ctx->ring_slot;
+    if (s < 0 || ctx->ring_done[s] || ctx->stream == ctx->ring_stream[s]) return VK_OK;
+    if (hipEventQuery(ctx->ring_ev[s]) == hipSuccess) { ctx->ring_done[s] = true; return VK_OK; }
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_ev[s], 0));
     return VK_OK;
 }
 
@@ -762,6 +790,8 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.rank = rank; L.nranks = nranks;
     {
         int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts, dt_scale);
+        if (orc) return orc;
+        orc = order_wait(ctx);
         if (orc) return orc;
         L.tile_order = ctx->d_order;
     }
@@ -916,6 +946,7 @@ int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n) {
     if (n != ctx->order.size() || !ctx->d_order) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: no order of that size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipDeviceSynchronize());
     for (uint32_t q = 0; q < n; q++) { ctx->order[q] = order[q]; ctx->order_pos[order[q]] = q; }
     HIP_TRY(ctx, hipMemcpy(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -950,6 +981,10 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
             int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
             if (orc) return orc;
         }
+    }
+    {
+        int owc = order_wait(ctx);
+        if (owc) return owc;
     }
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
