@@ -165,6 +165,12 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
  * frames marched before a camera change are un-tiled as they were dealt: deliver them before the next
  * partition call under the new camera (vokselis_amd/dist.py drains its pipeline at that point). */
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride);
+/* The order tables are versioned: vk_partition_epoch returns the epoch of the order the last partition / render call
+ * used (it changes with the camera), and vk_untile_epoch scatters with the tables of that epoch -- the library keeps
+ * the last 16 -- so a pipelined driver can keep marching under a new camera while older frames are still being
+ * gathered, and deliver each frame under the order it was dealt with. */
+int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch);
+int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, uint32_t epoch);
 
 /* ---- present + screenshot ---------------------------------------- */
 /* Context::render's present pass (src/context.rs:251-297, shaders/present.wgsl:23-35,111-119): bilinear

@@ -257,6 +257,52 @@ def test_tile_parallel_renderer_over_rccl_world1(V, O):
             dist.destroy_process_group()
 
 
+def test_tile_parallel_renderer_orbiting_camera(V, O):
+    """A camera that changes every frame: each frame is dealt under its own tile order and delivered (later, while
+    newer frames are already marching) under that order's epoch -- no pipeline drain.  More camera changes than the
+    library keeps order tables for (16) pass through while at most two batches are pending."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from vokselis_amd.dist import TileParallelRenderer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    W, H = 320, 200
+    vol = O.volume_standin_u8(64)
+    ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    ref_ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    try:
+        for c in (ctx, ref_ctx):
+            V.VolumeTexture(c, vol); c.update()
+        expect, bad = [], []
+
+        def check(k):
+            if not (ctx.read_backbuffer().view(np.uint16) == expect[k]).all():
+                bad.append(k)
+
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pipe = V.RaycastPipeline(dt_scale=0.5)
+            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=4, frames_in_flight=4, on_frame=check)
+            for k in range(40):
+                for c in (ctx, ref_ctx):
+                    c.camera.set_yaw(1.0 + 0.15 * k); c.camera.set_zoom(1.0 + 0.03 * k); c.update()
+                pipe.record(ref_ctx)
+                expect.append(ref_ctx.read_backbuffer().view(np.uint16).copy())
+                tpr.submit(k)
+            tpr.flush()
+        assert tpr._delivered == 40 and not bad, bad
+    finally:
+        ctx.close(); ref_ctx.close()
+        if created:
+            dist.destroy_process_group()
+
+
 def _tpr_two_ranks_worker(rank, world, port, q):
     """One of two processes sharing cuda:0: the production TileParallelRenderer with rank/world = (rank, 2); only the
     wire is replaced (gloo through host memory -- RCCL refuses two ranks on one device)."""

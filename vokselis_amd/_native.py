@@ -47,6 +47,8 @@ SYMBOLS = {
     "vk_partition_order": (C.c_int, [_vp, C.c_int, _u32, C.POINTER(_u32), _u32]),
     "vk_partition_active": (C.c_int, [_vp, C.c_int, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_untile": (C.c_int, [_vp, _vp, _u32, _u32, _u32]),
+    "vk_untile_epoch": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32]),
+    "vk_partition_epoch": (C.c_int, [_vp, C.POINTER(_u32)]),
     "vk_present": (C.c_int, [_vp, _u32, _u32, C.c_int]),
     "vk_capture_frame": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_readback": (C.c_int, [_vp, _vp, _sz]),

@@ -64,6 +64,9 @@ struct vk_ctx {
     hipEvent_t ring_ev[16] = {};     // slot uploaded
     hipStream_t ring_stream[16] = {};
     bool ring_done[16] = {};
+    uint32_t ring_active[16] = {};   // order_active of the slot
+    uint32_t ring_epoch[16] = {};    // the epoch (count of order changes) that filled the slot
+    uint32_t order_epoch = 0;        // epoch of the current slot; epoch e lives in slot e % 16 while order_epoch - e < 16
 
     // present targets (next row N1/N2)
     uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
@@ -706,12 +709,13 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
         if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
         ctx->d_ring = ctx->h_ring = nullptr; ctx->d_order = ctx->d_order_pos = nullptr;
         ctx->d_order_cap = 0; ctx->ring_slot = -1;
+        for (uint32_t &e : ctx->ring_epoch) e = 0;  // older epochs are gone with the old ring
         HIP_TRY(ctx, hipMalloc(&ctx->d_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
         HIP_TRY(ctx, hipHostMalloc(&ctx->h_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
         ctx->d_order_cap = n;
     }
     const size_t cap = ctx->d_order_cap;
-    const int slot = (ctx->ring_slot + 1) % kOrderRing;
+    const int slot = (int)((ctx->order_epoch + 1u) % (uint32_t)kOrderRing);  // epoch e lives in slot e % kOrderRing
     // the slot's previous upload (kOrderRing cameras ago) has long completed; waiting on it also makes the pinned
     // staging safe to rewrite.  Launches that still READ that old slot would have to be > kOrderRing - 1 cameras
     // behind: the N > 1 driver drains at every camera change, single-stream use is stream-ordered.
@@ -724,6 +728,8 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     HIP_TRY(ctx, hipEventRecord(ctx->ring_ev[slot], ctx->stream));
     ctx->ring_stream[slot] = ctx->stream;
     ctx->ring_done[slot] = false;
+    ctx->ring_active[slot] = n_active;
+    ctx->ring_epoch[slot] = ++ctx->order_epoch;
     ctx->ring_slot = slot;
     ctx->d_order = ds;
     ctx->d_order_pos = ds + cap;
@@ -965,35 +971,57 @@ int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *orde
     return VK_OK;
 }
 
-int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride) {
+static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, bool by_epoch, uint32_t epoch) {
     if (!ctx || !gathered) return fail(ctx, VK_ERR_INVALID, "vk_untile: NULL argument");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
     if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "vk_untile: no camera (the tile order follows the camera)");
     const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
-    {
+    const uint32_t *d_pos = nullptr;
+    uint32_t n_active = 0;
+    if (by_epoch) {
+        const int s = (int)(epoch % 16u);
+        if (epoch == 0 || ctx->order_epoch - epoch >= 16u || ctx->ring_epoch[s] != epoch || !ctx->d_ring)
+            return fail(ctx, VK_ERR_INVALID, "vk_untile_epoch: that order is no longer held (more than 15 order changes ago)");
+        d_pos = ctx->d_ring + (size_t)s * 2 * ctx->d_order_cap + ctx->d_order_cap;
+        n_active = ctx->ring_active[s];
+        if (!ctx->ring_done[s] && ctx->stream != ctx->ring_stream[s]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_ev[s], 0));
+    } else {
         // The un-tile follows the order the partitions were marched with: the tables of the LAST partition call,
-        // not those of a camera uploaded since (frames still in the pipeline when the camera moves are delivered
-        // as they were dealt).  Only a context that has never partitioned this frame shape derives them here.
+        // not those of a camera uploaded since.  Only a context that has never partitioned this frame shape derives them here.
         const size_t n_tiles = (size_t)tiles_x * ((ctx->height + tile_size - 1) / tile_size);
         if (!ctx->d_order_pos || ctx->order.size() != n_tiles) {
             int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
             if (orc) return orc;
         }
-    }
-    {
         int owc = order_wait(ctx);
         if (owc) return owc;
+        d_pos = ctx->d_order_pos;
+        n_active = ctx->order_active;
     }
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos, ctx->order_active);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, d_pos, n_active);
     else
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, ctx->d_order_pos, ctx->order_active);
+        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, d_pos, n_active);
     HIP_TRY(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride) {
+    return untile_common(ctx, gathered, tile_size, nranks, slot_stride, false, 0);
+}
+
+int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, uint32_t epoch) {
+    return untile_common(ctx, gathered, tile_size, nranks, slot_stride, true, epoch);
+}
+
+int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch) {
+    if (!ctx || !epoch) return VK_ERR_INVALID;
+    *epoch = ctx->order_epoch;
     return VK_OK;
 }
 

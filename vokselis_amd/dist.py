@@ -14,6 +14,8 @@ the collective's stream while batch g+1 is marched, and the root un-tiles batch 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import _native as N
@@ -129,7 +131,8 @@ class TileParallelRenderer:
         self.fg = (gather_cls or FrameGather)(bb.width, bb.height, tile_size, dtype, dev, root=root, group=group, batch=batch)
         assert self.fg.slots == partition_slots(bb.width, bb.height, tile_size, self.fg.world)
         self._esize = 4 if bb.format == N.OUT_RGBA32F else 2
-        self._pending = None  # (set, n, count, work) of the batch whose un-tile is still owed
+        self._pending = None  # (set, n, count, work, order epoch) of the batch whose un-tile is still owed
+        self._epoch = 0
         self._active, self._active_key = None, None
         self._n = None        # active slots of the batch being filled
         self._set, self._filled = 0, 0
@@ -155,13 +158,16 @@ class TileParallelRenderer:
             raise RuntimeError("TileParallelRenderer must be driven on the torch stream it was created on")
         key = (id(self.ctx), self.ctx.camera_epoch)
         if self._active_key != key:
-            # A new camera re-deals the tiles: frames marched under the old order must be gathered AND un-tiled
-            # before the library rebuilds its order tables (which the next call below does), so the pipeline is
-            # drained here.  A camera that moves every frame therefore runs one frame at a time.
-            if self._active_key is not None:
-                self.flush()
+            # A new camera re-deals the tiles (other order, maybe another active set): the batch being filled is
+            # closed at this point, so a batch holds frames of ONE order, and it is un-tiled later under that
+            # order's epoch (the library keeps the tables of the last 16 orders) -- the pipeline keeps running.
+            if self._filled:
+                self._launch_batch()
             self._active = self.ctx.partition_active(fg.ts, fg.world, self.pipe.mode)[1]  # per uploaded camera; cached in the library too
             self._active_key = key
+            e = C.c_uint32()
+            N.check(self.ctx.handle, N.lib().vk_partition_epoch(self.ctx.handle, C.byref(e)))
+            self._epoch = e.value
         n = self._active
         self._n = n
         if n > 0:
@@ -187,13 +193,13 @@ class TileParallelRenderer:
                 self._main.wait_event(self._done[set_][b])  # the gather (ordered after the main stream) sees every frame
         work = fg.start(set_, n, count) if n > 0 else None
         self._finish_pending()
-        self._pending = (set_, n, count, work)
+        self._pending = (set_, n, count, work, self._epoch)
         self._set, self._filled = set_ ^ 1, 0
 
     def _finish_pending(self):
         if self._pending is None:
             return
-        set_, n, count, work = self._pending
+        set_, n, count, work, epoch = self._pending
         if work is not None:
             work.wait()  # orders the current stream after the collective
         if self._fif > 1:
@@ -206,14 +212,14 @@ class TileParallelRenderer:
                 base = fg.buffers(n)[1][set_].data_ptr()
                 frame_bytes = n * fg.ts * fg.ts * 4 * self._esize
                 for b in range(count):  # every frame of the batch materialises in the root's backbuffer, in order
-                    N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, base + b * frame_bytes, fg.ts, fg.world, fg.batch * n))
+                    N.check(self.ctx.handle, N.lib().vk_untile_epoch(self.ctx.handle, base + b * frame_bytes, fg.ts, fg.world, fg.batch * n, epoch))
                     if self.on_frame is not None:
                         self.on_frame(self._delivered + b)
             else:
                 # no tile touches the cube: the un-tile only clears (it reads no slot), once per frame
                 dummy = fg.buffers(1)[1][0].data_ptr()
                 for b in range(count):
-                    N.check(self.ctx.handle, N.lib().vk_untile(self.ctx.handle, dummy, fg.ts, fg.world, fg.batch))
+                    N.check(self.ctx.handle, N.lib().vk_untile_epoch(self.ctx.handle, dummy, fg.ts, fg.world, fg.batch, epoch))
                     if self.on_frame is not None:
                         self.on_frame(self._delivered + b)
         self._delivered += count
