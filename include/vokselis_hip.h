@@ -61,9 +61,12 @@ enum vk_layout {
     VK_LAYOUT_PACKED_PAIRS = 3, /* u8 volumes: cells hold 4 (tap, x-delta) f16 pairs, 16 B */
     VK_LAYOUT_BRICKED = 4, /* dense 8^3 bricks + 1-voxel apron (9^3): 1.42x the dense bytes, 8 taps from one
                               brick as four x-pair loads; the most compact layout (no skip map) */
-    VK_LAYOUT_QUADS = 5 /* every element holds a voxel's 2x2 (y,z) neighbourhood: 8 taps = two consecutive elements
+    VK_LAYOUT_QUADS = 5, /* every element holds a voxel's 2x2 (y,z) neighbourhood: 8 taps = two consecutive elements
                            = ONE 8/16-byte load; 4.5x the dense bytes; pays when the image has more rays than the volume has
                            voxel columns (no skip map; never AUTO's choice) */
+    VK_LAYOUT_STAGED = 6 /* dense 8^3 bricks (no apron; one copy per major ray axis) that every wave stages through LDS with
+                            coalesced 16-byte LDS-DMA loads, taps read with ds_read: the layout for volumes far larger than
+                            the caches (AUTO's choice above 4 GiB of cells; no skip map) */
 };
 
 enum vk_render_flags {
@@ -71,7 +74,8 @@ enum vk_render_flags {
     VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
     VK_RENDER_SAFE = 4,     /* force the clamped / 64-bit-offset kernel variant */
     VK_RENDER_FORCE_SKIP = 8, /* skip even when < 10 % of the cells are transparent (default: auto) */
-    VK_RENDER_DEBUG_TRIPS = 16 /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
+    VK_RENDER_DEBUG_TRIPS = 16, /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
+    VK_RENDER_DEBUG_FALLBACK = 32 /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */
@@ -200,6 +204,10 @@ int vk_simt_census(vk_ctx *ctx, uint64_t out[4]);
 /* Debug: override the tile order table (experiments on launch order). */
 int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n);
 int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks);
+/* Debug / tuning knobs of the staged march: "stage_cap_bytes" (LDS window per wave, default 12288),
+ * "stage_slab_log2" (a round is a slab of 2^k cells along the wave's major axis, default 3), "stage_copies_mask" (bit k: build the brick copy
+ * whose slow axis is k; applies to the next upload, default 7). */
+int vk_debug_set_param(vk_ctx *ctx, const char *name, double value);
 /* Per-pixel executed loop iterations of the last VK_RENDER_COUNT launch ([height][width] u32). */
 int vk_readback_steps(vk_ctx *ctx, uint32_t *dst);
 

@@ -53,7 +53,8 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
 
 
 def layouts(V):
-    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED, "Q": V.LAYOUT_QUADS}
+    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED, "Q": V.LAYOUT_QUADS,
+            "S8": V.LAYOUT_STAGED}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -446,7 +447,7 @@ def test_tile_parallel_renderer_frames_in_flight_stress(V, O):
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)
-    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR, V.LAYOUT_BRICKED, V.LAYOUT_QUADS):
+    for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR, V.LAYOUT_BRICKED, V.LAYOUT_QUADS, V.LAYOUT_STAGED):
         img, steps, _ = gpu_render(V, cameras["bonsai_1x1"], vol, 64, 64, dt=0.5, layout=lay)
         assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all()
     # a dense-core f16 volume exercises the early-out and the skip map's 0.1 threshold
@@ -456,6 +457,63 @@ def test_f16_volume(V, O, golden, cameras):
     ref, rsteps, rsamp = O.render(cameras["bonsai_1x1"], core, 96, 96, dt_scale=0.5)
     img, steps, (s_ref, s_samp) = gpu_render(V, cameras["bonsai_1x1"], core, 96, 96, dt=0.5)
     assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all() and s_samp == int(rsamp.sum())
+
+
+def _render_with_params(V, cam, vol, W, H, dt, layout, params=(), flags=0):
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        for k, v in params:
+            ctx.set_param(k, v)
+        V.VolumeTexture(ctx, vol, layout=layout)
+        ctx.set_camera_blob(cam)
+        ctx.reset_step_counts()
+        V.RaycastPipeline(dt_scale=dt, flags=flags | V.RENDER_COUNT).record(ctx)
+        img, steps = ctx.read_backbuffer(), ctx.read_steps()
+        census = ctx.simt_census()
+        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+        V.RaycastPipeline(dt_scale=dt, flags=flags).record(ctx)
+        assert (ctx.read_backbuffer().view(np.uint32) == img.view(np.uint32)).all(), "production kernel differs from the instrumented one"
+        return img, steps, census
+    finally:
+        ctx.close()
+
+
+def test_staged_bricks_equal_linear_bitwise(V, O, golden_volumes):
+    """VK_LAYOUT_STAGED (8^3 bricks staged through LDS, vk_staged.hpp) against the dense LINEAR kernel: same taps,
+    same arithmetic, so frames and trip counts are bitwise equal -- for every window size (LDS budget down to
+    one that forces single-step rounds and the global-memory fallback), round length and set of brick copies,
+    on u8 and f16 volumes, cubic and not, with cameras outside, inside and axis-aligned."""
+    z, y, x = np.meshgrid(np.arange(48), np.arange(40), np.arange(56), indexing="ij")
+    r2 = (x - 24) ** 2 + (y - 20) ** 2 + (z - 28) ** 2
+    core = np.where(r2 < 100, 0.95, np.where(r2 < 400, 0.3, 0.05)).astype(np.float16)  # [nz=48][ny=40][nx=56]
+    vols = {"standin64": O.volume_standin_u8(64), "fog_f16_32": O.volume_fog_f16(32), "core_f16": core,
+            "fog_u8_40x24x56": O.volume_fog_u8((40, 24, 56), seed=7, lo=20, span=12), "checker": golden_volumes["checker"]}
+    cams = {"bonsai": O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.5),
+            "inside": O.camera_blob(0.3, 0.4, 2.5, (0.5, 0.5, 0.5), 1.5),
+            "top": O.camera_blob(1.2, 1.45, 0.3, (0.5, 0.5, 0.5), 1.5),
+            "far": O.camera_blob(3.0, -0.6, 4.0, (0.5, 0.5, 0.5), 1.5)}
+    knobs = {"default": (), "tiny_window": (("stage_cap_bytes", 1024),), "thin_slabs": (("stage_slab_log2", 1), ("stage_cap_bytes", 4096)),
+             "thick_slabs": (("stage_slab_log2", 5), ("stage_cap_bytes", 32768)), "copy_x_only": (("stage_copies_mask", 1),),
+             "copy_y_only": (("stage_copies_mask", 2),), "copy_z_only": (("stage_copies_mask", 4),)}
+    W, H = 96, 64
+    saw_fallback = saw_short = False
+    for vname, vol in vols.items():
+        for cname, cam in cams.items():
+            for dt in (1.0, 0.37):
+                ref, rsteps, _ = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_LINEAR)
+                for kname, params in knobs.items():
+                    if kname != "default" and (cname, dt) not in (("bonsai", 0.37), ("top", 1.0)):
+                        continue
+                    img, steps, cen = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_STAGED, params)
+                    assert (steps == rsteps).all(), (vname, cname, dt, kname)
+                    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), (vname, cname, dt, kname)
+                    saw_fallback |= cen["wave_skip_iters"] > 0          # rounds served from global memory
+                    saw_short |= kname == "tiny_window" and cen["wave_sample_execs"] < 8 * cen["wave_loop_iters"]  # slabs thinner than asked for
+    assert saw_fallback and saw_short  # the degenerate paths were exercised, not just the fast one
+    # and against the oracle
+    ref, rsteps, _ = O.render(cams["bonsai"], vols["core_f16"], W, H, dt_scale=0.37)
+    img, steps, _ = _render_with_params(V, cams["bonsai"], vols["core_f16"], W, H, 0.37, V.LAYOUT_STAGED)
+    assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all()
 
 
 def test_device_fog_generator_is_bit_identical(V, O):

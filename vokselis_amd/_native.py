@@ -14,7 +14,7 @@ VK_OK = 0
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
 MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST, MODE_PROCEDURAL = 0, 1, 2
 OUT_RGBA32F, OUT_RGBA16F = 0, 1
-LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, LAYOUT_QUADS = 0, 1, 2, 3, 4, 5
+LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, LAYOUT_QUADS, LAYOUT_STAGED = 0, 1, 2, 3, 4, 5, 6
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 GEN_FOG, GEN_BONSAI_STANDIN = 0, 1
@@ -56,6 +56,7 @@ SYMBOLS = {
     "vk_step_counts_reset": (C.c_int, [_vp]),
     "vk_simt_census": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "vk_debug_set_tile_order": (C.c_int, [_vp, C.POINTER(_u32), _u32]),
+    "vk_debug_set_param": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "vk_debug_wave_trace": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _sz]),
     "vk_readback_steps": (C.c_int, [_vp, _vp]),
     "vk_timer_begin": (C.c_int, [_vp]),
@@ -83,6 +84,15 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64; if this library
+        # (linked against /opt/rocm's) is loaded first, a later `import torch` brings a second runtime into the
+        # process and whichever initialises second reports "no ROCm-capable device".  Loaded after torch, the
+        # dynamic loader resolves this library's libamdhip64.so.7 to the copy already in the process.  Processes
+        # that never import torch (the C++ host, a plain C consumer) are unaffected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export it

@@ -185,6 +185,10 @@ class Context:
     def sync(self):
         N.check(self._h, N.lib().vk_ctx_sync(self._h))
 
+    def set_param(self, name: str, value: float):
+        """Debug / tuning knob of the library (vk_debug_set_param)."""
+        N.check(self._h, N.lib().vk_debug_set_param(self._h, name.encode(), float(value)))
+
     # -- results
     def read_backbuffer(self) -> np.ndarray:
         """The backbuffer as [H, W, 4] float32 (RGBA32F) or float16 (RGBA16F)."""

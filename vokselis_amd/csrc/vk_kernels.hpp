@@ -45,7 +45,8 @@ constexpr int kDistRadius = 24;  // distance map saturates at kDistRadius + 1
 // four-load layouts are bound by the texture-address path rather than by HBM.
 // PAIRB: the two rgba16f volumes of the compute mode interleaved as 16-byte (density, normals) records in
 // 4^3 bricks: one nearest-neighbour step is ONE aligned 16-byte load.
-enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6, VOL_PAIRB = 7, VOL_Q8 = 8, VOL_QF16 = 9 };
+// S8U8 / S8F16: dense 8^3 bricks without apron, staged through LDS by the wave (vk_staged.hpp).
+enum VolKind : int { VOL_LINEAR_U8 = 0, VOL_LINEAR_F16 = 1, VOL_P8 = 2, VOL_P16 = 3, VOL_PF16 = 4, VOL_B9U8 = 5, VOL_B9F16 = 6, VOL_PAIRB = 7, VOL_Q8 = 8, VOL_QF16 = 9, VOL_S8U8 = 10, VOL_S8F16 = 11 };
 enum OutKind : int { OUT_RGBA32F = 0, OUT_RGBA16F = 1 };
 
 struct VolumeDesc {
@@ -81,7 +82,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
-    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds)
+    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
 };
 
@@ -346,7 +347,7 @@ struct RayState {
 static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
 
 struct Census {  // SIMT execution census + step counters (COUNT builds only)
-    uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0;
+    uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0, n_fb = 0;
 };
 
 // Runs at most `budget` trips of the reference loop (raycast_naive.wgsl:101-119) on the state and

@@ -1,0 +1,427 @@
+// vk_staged.hpp -- NAIVE_TRILINEAR for volumes far larger than the caches: 8^3 bricks staged through LDS.
+//
+// raycast_naive.wgsl:96-119 issues one texture fetch per step; on CDNA4 that is 8 taps, and once the volume no
+// longer fits the caches the four scattered x-pair loads per lane of the 9^3-brick kernel keep the texture-address
+// path busy (49 cache-line look-ups per wave-level load, profiles/r01_c4_b9_pmc_summary.txt).  Here a wave stages
+// the voxels its 64 rays are about to sample into LDS with coalesced 16-byte LDS-DMA loads and reads the taps with
+// ds_read:
+//
+//  * HBM layout: dense voxels in 8^3 bricks (u8: 16 x 8 x 8), NO apron; clamp-to-edge is a replicated border of
+//    kStagePad voxels baked in around the volume.  A brick is 64 "pieces" of 16 bytes (8 f16 / 16 u8 voxels along
+//    the copy's FAST axis); the 8 pieces of a 128-byte line are 8 consecutive rows along the MID axis, the 8 lines
+//    of a brick are its 8 slices along the SLOW axis.  There are up to three copies, one per SLOW axis: a wave
+//    uses the copy whose SLOW axis is the major axis of its rays, so the window it needs is a few slices thick,
+//    every fetched line is used, and the 8/16-voxel granularity of a piece falls on a lateral axis where the
+//    window is wide anyway.  (288 GB of HBM: three copies of 2048^3 u8 are 26 GB.)
+//  * LDS window: an axis-aligned box of voxels, dense, [slow][mid][fast], rows whole pieces -- so the window is
+//    contiguous in piece order and one global_load_lds_dwordx4 fills 64 consecutive pieces from 64 arbitrary
+//    source addresses.  No apron, no per-brick padding: the window holds what the rays need plus alignment.
+//  * Rounds are slabs of T cells along the wave's major axis (see march_staged_perm): the window's range along
+//    that axis is exact, its lateral range is a wave-reduced bounding box with a proven margin, so the step loop
+//    carries no residency test and no clamp.  A box that exceeds the LDS budget halves T; what even T = 1 cannot
+//    hold is served from global memory (always correct, slow, never on the benchmark configurations).
+//  * The arithmetic on the taps is that of march() (LINEAR / 9^3 layouts): frames are bitwise equal.
+#pragma once
+
+#include "vk_kernels.hpp"
+
+namespace vk {
+
+constexpr int kStagePad = 8;
+
+struct StagedDesc {
+    const unsigned char *copy[3];  // copy[k]: SLOW axis k, FAST axis (k+1)%3, MID axis (k+2)%3 (nullptr: not built)
+    uint32_t copy_of_major[3];     // copy used by a wave whose rays' major axis is x / y / z
+    uint32_t nv[3];                // padded voxel extent per axis (multiple of 8, >= n + kStagePad + 2)
+    uint32_t npf[3];               // per copy: 16-byte pieces along its FAST axis
+    uint32_t nbm[3];               // per copy: bricks along its MID axis
+    uint32_t cap_bytes;            // LDS window capacity = dynamic LDS of the launch
+    uint32_t slab_log2;            // a round is a slab of at most 1 << slab_log2 cells along the wave's major axis
+};
+
+// floor(q / d) = umulhi(q, kMagic[d]) for q * d < 2^32, d in [2, 64]
+__device__ const uint32_t kStageMagic[65] = {
+    0u, 0u, 2147483649u, 1431655766u, 1073741825u, 858993460u, 715827883u, 613566757u, 536870913u, 477218589u, 429496730u, 390451573u, 357913942u,
+    330382100u, 306783379u, 286331154u, 268435457u, 252645136u, 238609295u, 226050911u, 214748365u, 204522253u, 195225787u, 186737709u, 178956971u,
+    171798692u, 165191050u, 159072863u, 153391690u, 148102321u, 143165577u, 138547333u, 134217729u, 130150525u, 126322568u, 122713352u, 119304648u,
+    116080198u, 113025456u, 110127367u, 107374183u, 104755300u, 102261127u, 99882961u, 97612894u, 95443718u, 93368855u, 91382283u, 89478486u,
+    87652394u, 85899346u, 84215046u, 82595525u, 81037119u, 79536432u, 78090315u, 76695845u, 75350304u, 74051161u, 72796056u, 71582789u, 70409300u,
+    69273667u, 68174085u, 67108865u};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+
+// Wave-wide minimum / maximum, all 64 lanes active; the result is wave-uniform (read from lane 63).
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_take<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+    v = min(v, dpp_take<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+    v = min(v, dpp_take<0x141, 0xF>(v));  // row_half_mirror
+    v = min(v, dpp_take<0x140, 0xF>(v));  // row_mirror: every lane of a row holds the row's minimum
+    v = min(v, dpp_take<0x142, 0xA>(v));  // row_bcast:15 -> rows 1, 3
+    v = min(v, dpp_take<0x143, 0xC>(v));  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, dpp_take<0xB1, 0xF>(v));
+    v = max(v, dpp_take<0x4E, 0xF>(v));
+    v = max(v, dpp_take<0x141, 0xF>(v));
+    v = max(v, dpp_take<0x140, 0xF>(v));
+    v = max(v, dpp_take<0x142, 0xA>(v));
+    v = max(v, dpp_take<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Dense voxels -> one staged copy.  One thread per 16-byte piece, pieces enumerated in storage order.
+template <bool U8>
+__global__ __launch_bounds__(256) void pack_staged_kernel(const void *__restrict__ src, uint4 *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
+                                                          int slow, uint32_t npf, uint32_t nbm, uint64_t n_pieces) {
+    constexpr int VPP = U8 ? 16 : 8;
+    const int F = (slow + 1) % 3, M = (slow + 2) % 3, S = slow;
+    const int n[3] = {(int)nx, (int)ny, (int)nz};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_pieces; id += stride) {
+        const uint64_t brick = id >> 6;
+        const uint32_t w = (uint32_t)(id & 63u);
+        const uint32_t pf = (uint32_t)(brick % npf);
+        const uint64_t rest = brick / npf;
+        const uint32_t bm = (uint32_t)(rest % nbm), bs = (uint32_t)(rest / nbm);
+        int c[3];
+        c[M] = clampi((int)(bm * 8 + (w & 7u)) - kStagePad, 0, n[M] - 1);
+        c[S] = clampi((int)(bs * 8 + (w >> 3)) - kStagePad, 0, n[S] - 1);
+        union { uint4 u; uint8_t b[16]; uint16_t h[8]; } o;
+#pragma unroll
+        for (int e = 0; e < VPP; e++) {
+            c[F] = clampi((int)(pf * VPP) + e - kStagePad, 0, n[F] - 1);
+            const size_t idx = (size_t)c[0] + (size_t)nx * ((size_t)c[1] + (size_t)ny * (size_t)c[2]);
+            if (U8) o.b[e] = reinterpret_cast<const uint8_t *>(src)[idx];
+            else o.h[e] = reinterpret_cast<const uint16_t *>(src)[idx];
+        }
+        dst[id] = o.u;
+    }
+}
+
+// The 8 taps of a sample from the LDS window: pair k (two consecutive elements along the FAST axis) at byte
+// address a[k].  Eight naturally aligned element reads, in inline assembly: written in C++ the compiler merges the
+// two halves of a pair into one ds_read_b32 at 2-byte alignment, which is legal but slow on gfx950 (C4: 5.7 ms
+// with such reads, 2.8 ms with every address forced to a multiple of 4).  The loads are followed by their own
+// s_waitcnt, tied to the results, because the compiler does not count loads it cannot see.
+template <bool U8>
+__device__ __forceinline__ void lds_tap_pairs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t pr[4]) {
+    uint32_t l0, l1, l2, l3, h0, h1, h2, h3;
+    if constexpr (U8) {
+        asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %9\n\tds_read_u8 %3, %9 offset:1\n\t"
+                     "ds_read_u8 %4, %10\n\tds_read_u8 %5, %10 offset:1\n\tds_read_u8 %6, %11\n\tds_read_u8 %7, %11 offset:1"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    } else {
+        asm volatile("ds_read_u16 %0, %8\n\tds_read_u16 %1, %8 offset:2\n\tds_read_u16 %2, %9\n\tds_read_u16 %3, %9 offset:2\n\t"
+                     "ds_read_u16 %4, %10\n\tds_read_u16 %5, %10 offset:2\n\tds_read_u16 %6, %11\n\tds_read_u16 %7, %11 offset:2"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3));
+    constexpr int sh = U8 ? 8 : 16;
+    pr[0] = l0 | (h0 << sh); pr[1] = l1 | (h1 << sh); pr[2] = l2 | (h2 << sh); pr[3] = l3 | (h3 << sh);
+}
+
+// One sample's transfer function, colour and compositing: the statements of march() after the filter.
+__device__ __forceinline__ void composite_step(float v, float &A, float &Gr, float &Gg, float &Gb) {
+    const float a = transfer_alpha(v);
+    constexpr double kk = 6.28318 / 6.283185307179586476925;
+    constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
+    constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
+    const float cr = __builtin_amdgcn_cosf(a * pc0);
+    const float cg = __builtin_amdgcn_cosf(fmaf(a, pc1, pd1));
+    const float cb = __builtin_amdgcn_cosf(fmaf(a, pc2, pd2));
+    const float w = (1.0f - A) * a;  // :112-114
+    Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
+    A = A + w;
+}
+
+// The filter on four pairs along the copy's FAST axis: pair k sits at MID offset k & 1, SLOW offset k >> 1.
+// lerp x, then y, then z, as the oracle: c = fma(f, b - a, a).  For f16 taps `b - a` is written fma(b, 1, -a)
+// (the same single rounding) so that conversion, difference and lerp are two v_fma_mix_f32 per edge.
+template <bool U8, int PERM>
+__device__ __forceinline__ float filter_pairs(const uint32_t pr[4], float fx, float fy, float fz) {
+    constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
+    float c[2][2];  // [dy][dz] after the x lerp
+    if constexpr (U8) {
+        float tp[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                int d[3];
+                d[F] = e; d[M] = k & 1; d[S] = k >> 1;
+                tp[d[0] + 2 * d[1] + 4 * d[2]] = (float)((pr[k] >> (8 * e)) & 0xffu);
+            }
+        c[0][0] = fmaf(fx, tp[1] - tp[0], tp[0]); c[1][0] = fmaf(fx, tp[3] - tp[2], tp[2]);
+        c[0][1] = fmaf(fx, tp[5] - tp[4], tp[4]); c[1][1] = fmaf(fx, tp[7] - tp[6], tp[6]);
+    } else {
+        _Float16 hp[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                int d[3];
+                d[F] = e; d[M] = k & 1; d[S] = k >> 1;
+                union { uint16_t u; _Float16 h; } cv;
+                cv.u = (uint16_t)(pr[k] >> (16 * e));
+                hp[d[0] + 2 * d[1] + 4 * d[2]] = cv.h;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a = (float)hp[2 * j], b = (float)hp[2 * j + 1];
+            const float dlt = fmaf(b, 1.0f, -a);
+            c[j & 1][j >> 1] = fmaf(fx, dlt, a);
+        }
+    }
+    const float c0 = fmaf(fy, c[1][0] - c[0][0], c[0][0]), c1 = fmaf(fy, c[1][1] - c[0][1], c[0][1]);
+    float v = fmaf(fz, c1 - c0, c0);
+    if (U8) v = v * (1.0f / 255.0f);
+    return v;
+}
+
+// One step with the 8 taps read from the brick copy itself (global memory): the always-correct path for what the
+// window cannot serve.
+template <int VOL, int PERM>
+__device__ __forceinline__ float sample_global(const StagedDesc &D, const float p[3], const float fn[3]) {
+    constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
+    constexpr bool U8 = (VOL == VOL_S8U8);
+    constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
+    const unsigned char *const base = D.copy[PERM];
+    const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM];
+    const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
+    const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
+    const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+    uint32_t pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        pr[k] = 0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint32_t vf = (uint32_t)min(max(i[F] + kStagePad + e, 0), (int)D.nv[F] - 1);
+            const uint32_t vm = (uint32_t)min(max(i[M] + kStagePad + (k & 1), 0), (int)D.nv[M] - 1);
+            const uint32_t vs = (uint32_t)min(max(i[S] + kStagePad + (k >> 1), 0), (int)D.nv[S] - 1);
+            const uint32_t brick = (vf >> VSH) + npf * ((vm >> 3) + nbm * (vs >> 3));
+            const unsigned char *g = base + (((uint64_t)brick << 10) | (uint64_t)(((vs & 7u) << 7) | ((vm & 7u) << 4))) + (vf & ((1u << VSH) - 1u)) * BPV;
+            if (U8) pr[k] |= (uint32_t)*g << (8 * e);
+            else pr[k] |= (uint32_t)*reinterpret_cast<const uint16_t *>(g) << (16 * e);
+        }
+    }
+    return filter_pairs<U8, PERM>(pr, fx, fy, fz);
+}
+
+// The march of one wave on copy PERM (SLOW axis S = the wave's major axis).
+//
+// Rounds are SLABS of T cells along S, taken in the wave's direction of travel: in a round every ray takes the
+// steps whose sample cell lies in the slab (about 2T of them at dt_scale 0.5), rays that have not reached the slab
+// wait, rays that have ended are gone.  Synchronising on position instead of on the step index keeps the box thin
+// whatever the entry face: rays of an oblique bundle enter far apart along their major axis.
+//  * The window's S range is exact (the slab test is made on the very cell index a step samples).
+//  * Its lateral range is the bounding box, over the rays in the slab, of the segment from the ray's position now
+//    to where it crosses the slab's far plane (positions are linear in S: two fmas per axis), reduced over the wave
+//    (4 reductions) with 1/32 voxel of margin against the rounding of the accumulated position (<= 1e-3 voxel).
+//  * A box larger than the LDS budget halves T; at T = 1 the step is served from global memory.  Rays that do not
+//    travel with the wave along S (opposite sign, or fewer than 0.2 cells per step: a bounded lateral slope is what
+//    bounds the box) are marched from global memory after the others -- adjacent pixels do not produce such rays
+//    at any sane field of view; the path exists for safety.
+template <int VOL, int PERM, bool COUNT>
+__device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane) {
+    constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
+    constexpr bool U8 = (VOL == VOL_S8U8);
+    constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
+    extern __shared__ unsigned char stage_win[];
+    const uint32_t win_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage_win;  // LDS byte address of the window
+    float t = r.t, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    float p[3] = {r.px, r.py, r.pz};
+    const float s[3] = {r.sx, r.sy, r.sz}, t1 = r.t1, dt = r.dt;
+    const float fn[3] = {(float)V.nx, (float)V.ny, (float)V.nz};
+    const unsigned char *const base = D.copy[PERM];
+    const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM], cap = D.cap_bytes;
+    const int T0 = 1 << D.slab_log2;
+    const int nvm1[3] = {(int)D.nv[0] - 1, (int)D.nv[1] - 1, (int)D.nv[2] - 1};
+
+    alive = alive && (t < t1 && A < 0.95f);
+    const float duS = s[S] * fn[S];  // cells per step along S
+    const bool dir_up = __popcll(__ballot(alive && duS > 0.0f)) >= __popcll(__ballot(alive && duS < 0.0f));  // wave-uniform
+    const bool fit = alive && (dir_up ? duS >= 0.2f : duS <= -0.2f);
+    const float inv = fit ? 1.0f / duS : 0.0f;
+    const float ratM = (s[M] * fn[M]) * inv, ratF = (s[F] * fn[F]) * inv;  // lateral cells per cell of S
+
+    for (;;) {
+        const bool live = fit && (t < t1 && A < 0.95f);
+        if (__ballot(live) == 0ull) break;  // wave-uniform
+        const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
+        const int iS = cvt_floor_i32(uS);
+        // the slab starts at the rearmost live ray
+        const int sig = dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000);
+        int T = T0;
+        int clo = dir_up ? sig : sig - T + 1;
+        const bool inslab = live && (uint32_t)(iS - clo) < (uint32_t)T;
+        // lateral bounds of the rays in the slab: from here to the slab's far plane
+        const float e = (dir_up ? (float)(clo + T) : (float)clo) - uS;
+        const float eM = fmaf(e, ratM, uM), eF = fmaf(e, ratF, uF);
+        const int kMl = cvt_floor_i32(fminf(uM, eM) * 64.0f), kMh = cvt_floor_i32(fmaxf(uM, eM) * 64.0f);
+        const int kFl = cvt_floor_i32(fminf(uF, eF) * 64.0f), kFh = cvt_floor_i32(fmaxf(uF, eF) * 64.0f);
+        const int bMl = wave_min_i32(inslab ? kMl : 0x7fffffff) - 2, bMh = wave_max_i32(inslab ? kMh : (int)0x80000000) + 3;
+        const int bFl = wave_min_i32(inslab ? kFl : 0x7fffffff) - 2, bFh = wave_max_i32(inslab ? kFh : (int)0x80000000) + 3;
+        const int ilM = min(max((bMl >> 6) + kStagePad, 0), nvm1[M]), ihM = min(max((bMh >> 6) + kStagePad + 1, 0), nvm1[M]);  // + 1: the upper tap
+        const int ilF = min(max((bFl >> 6) + kStagePad, 0), nvm1[F]), ihF = min(max((bFh >> 6) + kStagePad + 1, 0), nvm1[F]);
+        const uint32_t pf0 = (uint32_t)ilF >> VSH, Efp = ((uint32_t)ihF >> VSH) - pf0 + 1u, Em = (uint32_t)(ihM - ilM) + 1u;
+        // the thickest slab whose box fits the window (scalar)
+        int ilS;
+        uint32_t Es;
+        bool fits;
+        for (;;) {
+            clo = dir_up ? sig : sig - T + 1;
+            ilS = min(max(clo + kStagePad, 0), nvm1[S]);
+            Es = (uint32_t)(min(max(clo + T + kStagePad, 0), nvm1[S]) - ilS) + 1u;  // cells clo .. clo+T-1 and the upper tap
+            fits = Efp <= 64u && Em <= 64u && Es * Em * Efp * 16u <= cap;
+            if (fits || T == 1) break;
+            T >>= 1;
+        }
+        if (fits) {
+            // ---- fill: piece q of the window [slow][mid][fast-piece] <- its 16 bytes in the copy
+            const uint32_t NP = Es * Em * Efp;
+            const uint32_t mgF = kStageMagic[Efp], mgM = kStageMagic[Em];
+            for (uint32_t q0 = 0; q0 < NP; q0 += 64u) {
+                const uint32_t q = q0 + lane;
+                if (q < NP) {
+                    const uint32_t rr = Efp == 1u ? q : __umulhi(q, mgF);
+                    const uint32_t f = q - rr * Efp;
+                    const uint32_t ss = Em == 1u ? rr : __umulhi(rr, mgM);
+                    const uint32_t m = rr - ss * Em;
+                    const uint32_t mm = (uint32_t)ilM + m, sv = (uint32_t)ilS + ss;
+                    const uint32_t brick = pf0 + f + npf * ((mm >> 3) + nbm * (sv >> 3));
+                    const unsigned char *g = base + (((uint64_t)brick << 10) | (uint64_t)(((sv & 7u) << 7) | ((mm & 7u) << 4)));
+                    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)(stage_win + q0 * 16u), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- the steps inside the slab, taps from the window
+            const int rowB = (int)(Efp * 16u), sliceB = (int)(Em * Efp * 16u);
+            const int cbase = (kStagePad - ilS) * sliceB + (kStagePad - ilM) * rowB + (kStagePad - (int)(pf0 << VSH)) * BPV + (int)win_lds;
+            if (live) {
+                for (;;) {
+                    if (!(t < t1 && A < 0.95f)) break;
+                    const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
+                    const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
+                    if ((uint32_t)(i[S] - clo) >= (uint32_t)T) break;  // left the slab (or has not reached it)
+                    const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+                    const int a0 = __mul24(i[S], sliceB) + (__mul24(i[M], rowB) + (i[F] * BPV + cbase));  // |operands| < 2^23
+                    uint32_t pr[4];
+                    lds_tap_pairs<U8>((uint32_t)a0, (uint32_t)(a0 + rowB), (uint32_t)(a0 + sliceB), (uint32_t)(a0 + sliceB + rowB), pr);
+                    const float v = filter_pairs<U8, PERM>(pr, fx, fy, fz);
+                    composite_step(v, A, Gr, Gg, Gb);
+                    if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
+                    p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
+                    t = t + dt;
+                }
+            }
+        } else if (live && iS == sig) {
+            // ---- even a one-cell slab exceeds the window: the rearmost rays take one step from global memory
+            const float v = sample_global<VOL, PERM>(D, p, fn);
+            composite_step(v, A, Gr, Gg, Gb);
+            if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
+            p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
+            t = t + dt;
+        }
+        if (COUNT && wave_leader()) { cs.w_outer++; if (!fits) cs.w_inner++; cs.w_sample += (uint32_t)T; }
+    }
+    // rays that do not travel with the wave along S
+    if (__ballot(alive && !fit) != 0ull) {
+        if (alive && !fit) {
+            while (t < t1 && A < 0.95f) {
+                const float v = sample_global<VOL, PERM>(D, p, fn);
+                composite_step(v, A, Gr, Gg, Gb);
+                if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
+                p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
+                t = t + dt;
+            }
+        }
+    }
+    r.t = t; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+}
+
+// fs_main (raycast_naive.wgsl:83-125) on the staged layout.  Same ray set-up, output and counters as
+// raymarch_naive_kernel; no lane leaves before the march: all 64 take part in the reductions and the fills.
+template <int VOL, int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_staged_kernel(const LaunchDesc L, const VolumeDesc V, const StagedDesc D) {
+    static_assert(VOL == VOL_S8U8 || VOL == VOL_S8F16, "staged layouts");
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x;
+    const PixelMap pm = map_pixel(L, lb, lane);
+    {
+        const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
+        if (bx0 + 8 <= L.cull_x0 || bx0 >= L.cull_x1 || by0 + 8 <= L.cull_y0 || by0 >= L.cull_y1) {  // wave-uniform
+            if (!pm.valid) return;
+            store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
+            if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
+            return;
+        }
+    }
+    RayState r;
+    r.t = 0.0f; r.t1 = 0.0f; r.dt = 1.0f; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
+    r.A = 0.0f; r.Gr = r.Gg = r.Gb = 0.0f; r.out = 0;
+    bool hit = false;
+    if (pm.valid) {
+        // --- ray: SURVEY A.1 step 1, as raymarch_naive_kernel ---
+        float fxp = (float)pm.x + 0.5f, fyp = (float)pm.y + 0.5f;
+        float ndcx = (2.0f * fxp) / (float)L.W - 1.0f;
+        float ndcy = 1.0f - (2.0f * fyp) / (float)L.H;
+        float q[4];
+        mat4_mul_vec4(L.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
+        const float eye[3] = {L.eye[0], L.eye[1], L.eye[2]};
+        float dir[3] = {q[0] / q[3] - eye[0], q[1] / q[3] - eye[1], q[2] / q[3] - eye[2]};
+        normalize3(dir[0], dir[1], dir[2]);
+        float t0, t1;
+        intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
+        if (!(t0 > t1)) {  // :91-93
+            t0 = fmaxf(t0, 0.0f);  // :94
+            const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+            float dtx = 1.0f / (fnx * fabsf(dir[0]));
+            float dty = 1.0f / (fny * fabsf(dir[1]));
+            float dtz = 1.0f / (fnz * fabsf(dir[2]));
+            const float dt = L.dt_scale * fminf(dtx, fminf(dty, dtz));  // :97-99
+            r.t = t0; r.t1 = t1; r.dt = dt;
+            r.px = eye[0] + t0 * dir[0]; r.py = eye[1] + t0 * dir[1]; r.pz = eye[2] + t0 * dir[2];  // :100
+            r.sx = dir[0] * dt; r.sy = dir[1] * dt; r.sz = dir[2] * dt;  // :118
+            hit = true;
+        }
+    }
+    // the wave's major axis (cells per step), by majority of its rays: selects the copy
+    const float ax = fabsf(r.sx) * (float)V.nx, ay = fabsf(r.sy) * (float)V.ny, az = fabsf(r.sz) * (float)V.nz;
+    const int mj = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const int c0 = __popcll(__ballot(hit && mj == 0)), c1 = __popcll(__ballot(hit && mj == 1)), c2 = __popcll(__ballot(hit && mj == 2));
+    Census cs;
+    if (c0 + c1 + c2 != 0) {  // wave-uniform
+        const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
+        const uint32_t copy = D.copy_of_major[major];
+        if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane);
+        else if (copy == 1u) march_staged_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane);
+        else march_staged_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane);
+    }
+    if (!pm.valid) return;
+    float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+    if (hit) {
+        Cr = linear_to_srgb(fmaf(0.5f, r.Gr, 0.5f * r.A));  // :121-123
+        Cg = linear_to_srgb(fmaf(0.5f, r.Gg, 0.5f * r.A));
+        Cb = linear_to_srgb(fmaf(0.5f, r.Gb, 0.5f * r.A));
+    }
+    store_pixel<OUT>(L.out, pm.out_index, Cr, Cg, Cb, 1.0f);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 2u) ? cs.n_fb : ((L.debug_flags & 1u) ? cs.n_look : cs.n_iter);
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)cs.n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)cs.n_samp);
+            atomicAdd(&L.counters[2], (unsigned long long)cs.w_outer);   // rounds
+            atomicAdd(&L.counters[3], (unsigned long long)cs.w_inner);   // rounds served from global memory
+            atomicAdd(&L.counters[4], (unsigned long long)cs.w_sample);  // sum of K over rounds
+            atomicAdd(&L.counters[5], (unsigned long long)cs.n_look);
+        }
+    }
+}
+
+}  // namespace vk
