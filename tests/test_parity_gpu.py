@@ -492,8 +492,8 @@ def test_staged_bricks_equal_linear_bitwise(V, O, golden_volumes):
             "inside": O.camera_blob(0.3, 0.4, 2.5, (0.5, 0.5, 0.5), 1.5),
             "top": O.camera_blob(1.2, 1.45, 0.3, (0.5, 0.5, 0.5), 1.5),
             "far": O.camera_blob(3.0, -0.6, 4.0, (0.5, 0.5, 0.5), 1.5)}
-    knobs = {"default": (), "tiny_window": (("stage_cap_bytes", 1024),), "thin_slabs": (("stage_slab_log2", 1), ("stage_cap_bytes", 4096)),
-             "thick_slabs": (("stage_slab_log2", 5), ("stage_cap_bytes", 32768)), "copy_x_only": (("stage_copies_mask", 1),),
+    knobs = {"default": (), "tiny_window": (("stage_cap_bytes", 1024),), "thin_slabs": (("stage_slab_cells", 2), ("stage_cap_bytes", 4096)),
+             "thick_slabs": (("stage_slab_cells", 27), ("stage_cap_bytes", 32768)), "copy_x_only": (("stage_copies_mask", 1),),
              "copy_y_only": (("stage_copies_mask", 2),), "copy_z_only": (("stage_copies_mask", 4),)}
     W, H = 96, 64
     saw_fallback = saw_short = False

@@ -29,7 +29,7 @@ struct vk_ctx {
     void *vol = nullptr, *vol2 = nullptr;  // cells / dense voxels / pair
     void *scopy[3] = {nullptr, nullptr, nullptr};  // VK_LAYOUT_STAGED: one brick copy per slow axis
     StagedDesc sdesc{};
-    uint32_t stage_cap_bytes = 12288, stage_slab_log2 = 3, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
+    uint32_t stage_cap_bytes = 10240, stage_slab_cells = 8, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
     uint8_t *dist = nullptr;
     uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
     size_t vol_bytes = 0;
@@ -682,7 +682,7 @@ template <int VOL>
 static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     StagedDesc D = ctx->sdesc;
     D.cap_bytes = std::min(std::max(ctx->stage_cap_bytes & ~15u, 1024u), 65536u);
-    D.slab_log2 = std::min(ctx->stage_slab_log2, 5u);
+    D.slab_cells = std::min(std::max(ctx->stage_slab_cells, 1u), 32u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (f16) {
         if (count) hipLaunchKernelGGL((raymarch_staged_kernel<VOL, OUT_RGBA16F, true>), dim3(grid), dim3(64), D.cap_bytes, ctx->stream, L, V, D);
@@ -1219,7 +1219,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     if (!ctx || !name) return VK_ERR_INVALID;
     const std::string n(name);
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
-    else if (n == "stage_slab_log2") ctx->stage_slab_log2 = (uint32_t)value;     // cells per slab along the major axis, log2 (next render)
+    else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
     else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)
     else return fail(ctx, VK_ERR_INVALID, "vk_debug_set_param: unknown parameter " + n);
     return VK_OK;

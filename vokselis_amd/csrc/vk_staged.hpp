@@ -18,7 +18,7 @@
 //    source addresses.  No apron, no per-brick padding: the window holds what the rays need plus alignment.
 //  * Rounds are slabs of T cells along the wave's major axis (see march_staged_perm): the window's range along
 //    that axis is exact, its lateral range is a wave-reduced bounding box with a proven margin, so the step loop
-//    carries no residency test and no clamp.  A box that exceeds the LDS budget halves T; what even T = 1 cannot
+//    carries no residency test and no clamp.  A box that exceeds the LDS budget takes a thinner slab; what even T = 1 cannot
 //    hold is served from global memory (always correct, slow, never on the benchmark configurations).
 //  * The arithmetic on the taps is that of march() (LINEAR / 9^3 layouts): frames are bitwise equal.
 #pragma once
@@ -36,7 +36,7 @@ struct StagedDesc {
     uint32_t npf[3];               // per copy: 16-byte pieces along its FAST axis
     uint32_t nbm[3];               // per copy: bricks along its MID axis
     uint32_t cap_bytes;            // LDS window capacity = dynamic LDS of the launch
-    uint32_t slab_log2;            // a round is a slab of at most 1 << slab_log2 cells along the wave's major axis
+    uint32_t slab_cells;           // a round is a slab of at most this many cells along the wave's major axis
 };
 
 // floor(q / d) = umulhi(q, kMagic[d]) for q * d < 2^32, d in [2, 64]
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_staged_kernel(const void *__restrict
 // with such reads, 2.8 ms with every address forced to a multiple of 4).  The loads are followed by their own
 // s_waitcnt, tied to the results, because the compiler does not count loads it cannot see.
 template <bool U8>
-__device__ __forceinline__ void lds_tap_pairs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t pr[4]) {
+__device__ __forceinline__ void lds_tap_pairs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t lo[4], uint32_t hi[4]) {
     uint32_t l0, l1, l2, l3, h0, h1, h2, h3;
     if constexpr (U8) {
         asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %9\n\tds_read_u8 %3, %9 offset:1\n\t"
@@ -120,8 +120,26 @@ __device__ __forceinline__ void lds_tap_pairs(uint32_t a0, uint32_t a1, uint32_t
                      : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3));
-    constexpr int sh = U8 ? 8 : 16;
-    pr[0] = l0 | (h0 << sh); pr[1] = l1 | (h1 << sh); pr[2] = l2 | (h2 << sh); pr[3] = l3 | (h3 << sh);
+    lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3; hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3;
+}
+
+// f16 taps enter the filter straight from the low halves of their registers: v_fma_mix_f32 converts exactly and
+// rounds once, so  mix_sub(b, a) == (float)b - (float)a  and  mix_lerp(f, d, a) == fmaf(f, d, (float)a)  bit for bit.
+__device__ __forceinline__ float mix_sub(uint32_t b, uint32_t a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float mix_lerp(float f, float d, uint32_t a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(f), "v"(d), "v"(a));
+    return r;
+}
+// a * b + c on 24-bit signed operands (window addressing)
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // One sample's transfer function, colour and compositing: the statements of march() after the filter.
@@ -138,45 +156,31 @@ __device__ __forceinline__ void composite_step(float v, float &A, float &Gr, flo
     A = A + w;
 }
 
-// The filter on four pairs along the copy's FAST axis: pair k sits at MID offset k & 1, SLOW offset k >> 1.
-// lerp x, then y, then z, as the oracle: c = fma(f, b - a, a).  For f16 taps `b - a` is written fma(b, 1, -a)
-// (the same single rounding) so that conversion, difference and lerp are two v_fma_mix_f32 per edge.
+// The filter on four pairs along the copy's FAST axis: pair k = (lo[k], hi[k]) sits at MID offset k & 1, SLOW
+// offset k >> 1.  lerp x, then y, then z, as the oracle: c = fma(f, b - a, a).
 template <bool U8, int PERM>
-__device__ __forceinline__ float filter_pairs(const uint32_t pr[4], float fx, float fy, float fz) {
+__device__ __forceinline__ float filter_pairs(const uint32_t lo[4], const uint32_t hi[4], float fx, float fy, float fz) {
     constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
-    float c[2][2];  // [dy][dz] after the x lerp
-    if constexpr (U8) {
-        float tp[8];
+    uint32_t tp[8];  // tap index dx + 2*dy + 4*dz
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                int d[3];
-                d[F] = e; d[M] = k & 1; d[S] = k >> 1;
-                tp[d[0] + 2 * d[1] + 4 * d[2]] = (float)((pr[k] >> (8 * e)) & 0xffu);
-            }
-        c[0][0] = fmaf(fx, tp[1] - tp[0], tp[0]); c[1][0] = fmaf(fx, tp[3] - tp[2], tp[2]);
-        c[0][1] = fmaf(fx, tp[5] - tp[4], tp[4]); c[1][1] = fmaf(fx, tp[7] - tp[6], tp[6]);
-    } else {
-        _Float16 hp[8];
+        for (int e = 0; e < 2; e++) {
+            int d[3];
+            d[F] = e; d[M] = k & 1; d[S] = k >> 1;
+            tp[d[0] + 2 * d[1] + 4 * d[2]] = e ? hi[k] : lo[k];
+        }
+    float c[4];  // x edges at (dy, dz) = (0,0) (1,0) (0,1) (1,1)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                int d[3];
-                d[F] = e; d[M] = k & 1; d[S] = k >> 1;
-                union { uint16_t u; _Float16 h; } cv;
-                cv.u = (uint16_t)(pr[k] >> (16 * e));
-                hp[d[0] + 2 * d[1] + 4 * d[2]] = cv.h;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float a = (float)hp[2 * j], b = (float)hp[2 * j + 1];
-            const float dlt = fmaf(b, 1.0f, -a);
-            c[j & 1][j >> 1] = fmaf(fx, dlt, a);
+    for (int j = 0; j < 4; j++) {
+        if constexpr (U8) {
+            const float a = (float)tp[2 * j], b = (float)tp[2 * j + 1];
+            c[j] = fmaf(fx, b - a, a);
+        } else {
+            c[j] = mix_lerp(fx, mix_sub(tp[2 * j + 1], tp[2 * j]), tp[2 * j]);
         }
     }
-    const float c0 = fmaf(fy, c[1][0] - c[0][0], c[0][0]), c1 = fmaf(fy, c[1][1] - c[0][1], c[0][1]);
+    const float c0 = fmaf(fy, c[1] - c[0], c[0]), c1 = fmaf(fy, c[3] - c[2], c[2]);
     float v = fmaf(fz, c1 - c0, c0);
     if (U8) v = v * (1.0f / 255.0f);
     return v;
@@ -194,10 +198,9 @@ __device__ __forceinline__ float sample_global(const StagedDesc &D, const float 
     const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
     const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
     const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
-    uint32_t pr[4];
+    uint32_t lo[4], hi[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        pr[k] = 0;
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const uint32_t vf = (uint32_t)min(max(i[F] + kStagePad + e, 0), (int)D.nv[F] - 1);
@@ -205,11 +208,11 @@ __device__ __forceinline__ float sample_global(const StagedDesc &D, const float 
             const uint32_t vs = (uint32_t)min(max(i[S] + kStagePad + (k >> 1), 0), (int)D.nv[S] - 1);
             const uint32_t brick = (vf >> VSH) + npf * ((vm >> 3) + nbm * (vs >> 3));
             const unsigned char *g = base + (((uint64_t)brick << 10) | (uint64_t)(((vs & 7u) << 7) | ((vm & 7u) << 4))) + (vf & ((1u << VSH) - 1u)) * BPV;
-            if (U8) pr[k] |= (uint32_t)*g << (8 * e);
-            else pr[k] |= (uint32_t)*reinterpret_cast<const uint16_t *>(g) << (16 * e);
+            const uint32_t v = U8 ? (uint32_t)*g : (uint32_t)*reinterpret_cast<const uint16_t *>(g);
+            if (e) hi[k] = v; else lo[k] = v;
         }
     }
-    return filter_pairs<U8, PERM>(pr, fx, fy, fz);
+    return filter_pairs<U8, PERM>(lo, hi, fx, fy, fz);
 }
 
 // The march of one wave on copy PERM (SLOW axis S = the wave's major axis).
@@ -222,7 +225,7 @@ __device__ __forceinline__ float sample_global(const StagedDesc &D, const float 
 //  * Its lateral range is the bounding box, over the rays in the slab, of the segment from the ray's position now
 //    to where it crosses the slab's far plane (positions are linear in S: two fmas per axis), reduced over the wave
 //    (4 reductions) with 1/32 voxel of margin against the rounding of the accumulated position (<= 1e-3 voxel).
-//  * A box larger than the LDS budget halves T; at T = 1 the step is served from global memory.  Rays that do not
+//  * A box larger than the LDS budget takes a thinner slab; at T = 1 the step is served from global memory.  Rays that do not
 //    travel with the wave along S (opposite sign, or fewer than 0.2 cells per step: a bounded lateral slope is what
 //    bounds the box) are marched from global memory after the others -- adjacent pixels do not produce such rays
 //    at any sane field of view; the path exists for safety.
@@ -239,7 +242,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     const float fn[3] = {(float)V.nx, (float)V.ny, (float)V.nz};
     const unsigned char *const base = D.copy[PERM];
     const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM], cap = D.cap_bytes;
-    const int T0 = 1 << D.slab_log2;
+    const int T0 = (int)D.slab_cells;
     const int nvm1[3] = {(int)D.nv[0] - 1, (int)D.nv[1] - 1, (int)D.nv[2] - 1};
 
     alive = alive && (t < t1 && A < 0.95f);
@@ -279,23 +282,26 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
             Es = (uint32_t)(min(max(clo + T + kStagePad, 0), nvm1[S]) - ilS) + 1u;  // cells clo .. clo+T-1 and the upper tap
             fits = Efp <= 64u && Em <= 64u && Es * Em * Efp * 16u <= cap;
             if (fits || T == 1) break;
-            T >>= 1;
+            T--;
         }
         if (fits) {
-            // ---- fill: piece q of the window [slow][mid][fast-piece] <- its 16 bytes in the copy
-            const uint32_t NP = Es * Em * Efp;
-            const uint32_t mgF = kStageMagic[Efp], mgM = kStageMagic[Em];
-            for (uint32_t q0 = 0; q0 < NP; q0 += 64u) {
-                const uint32_t q = q0 + lane;
-                if (q < NP) {
-                    const uint32_t rr = Efp == 1u ? q : __umulhi(q, mgF);
-                    const uint32_t f = q - rr * Efp;
-                    const uint32_t ss = Em == 1u ? rr : __umulhi(rr, mgM);
-                    const uint32_t m = rr - ss * Em;
-                    const uint32_t mm = (uint32_t)ilM + m, sv = (uint32_t)ilS + ss;
-                    const uint32_t brick = pf0 + f + npf * ((mm >> 3) + nbm * (sv >> 3));
-                    const unsigned char *g = base + (((uint64_t)brick << 10) | (uint64_t)(((sv & 7u) << 7) | ((mm & 7u) << 4)));
-                    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)(stage_win + q0 * 16u), 16, 0, 0);
+            // ---- fill: piece (slice, q) of the window [slow][mid][fast-piece] <- its 16 bytes in the copy.  A lane keeps its
+            // (row, piece) of the slice, i.e. a 32-bit offset inside one layer of bricks, for every slice; the slice only
+            // moves the wave-uniform base: no vector arithmetic per load.
+            const uint32_t slicePieces = Em * Efp;
+            const uint32_t mgF = kStageMagic[Efp];
+            for (uint32_t j = 0; j < slicePieces; j += 64u) {
+                const uint32_t q = j + lane;
+                if (q < slicePieces) {
+                    const uint32_t m = Efp == 1u ? q : __umulhi(q, mgF);
+                    const uint32_t f = q - m * Efp;
+                    const uint32_t mm = (uint32_t)ilM + m;
+                    const uint32_t voff = ((pf0 + f + npf * (mm >> 3)) << 10) | ((mm & 7u) << 4);
+                    for (uint32_t si = 0; si < Es; si++) {
+                        const uint32_t sv = (uint32_t)ilS + si;
+                        const unsigned char *sbase = base + (((uint64_t)(npf * nbm) * (uint64_t)(sv >> 3)) << 10) + ((sv & 7u) << 7);
+                        __builtin_amdgcn_global_load_lds(sbase + voff, (__attribute__((address_space(3))) void *)(stage_win + (si * slicePieces + j) * 16u), 16, 0, 0);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -309,10 +315,10 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
                     if ((uint32_t)(i[S] - clo) >= (uint32_t)T) break;  // left the slab (or has not reached it)
                     const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
-                    const int a0 = __mul24(i[S], sliceB) + (__mul24(i[M], rowB) + (i[F] * BPV + cbase));  // |operands| < 2^23
-                    uint32_t pr[4];
-                    lds_tap_pairs<U8>((uint32_t)a0, (uint32_t)(a0 + rowB), (uint32_t)(a0 + sliceB), (uint32_t)(a0 + sliceB + rowB), pr);
-                    const float v = filter_pairs<U8, PERM>(pr, fx, fy, fz);
+                    const int a0 = mad_i24(i[S], sliceB, mad_i24(i[M], rowB, i[F] * BPV + cbase));  // |operands| < 2^23
+                    uint32_t lo[4], hi[4];
+                    lds_tap_pairs<U8>((uint32_t)a0, (uint32_t)(a0 + rowB), (uint32_t)(a0 + sliceB), (uint32_t)(a0 + sliceB + rowB), lo, hi);
+                    const float v = filter_pairs<U8, PERM>(lo, hi, fx, fy, fz);
                     composite_step(v, A, Gr, Gg, Gb);
                     if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
                     p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
