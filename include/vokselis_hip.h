@@ -176,6 +176,29 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
 int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch);
 int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, uint32_t epoch);
 
+/* Several frames in ONE launch.  The reference keeps frames in flight through its queue (src/lib.rs:178-194 submits a
+ * frame per RedrawRequested without waiting); here the grid itself spans n_frames frames, each with its own camera
+ * (`cameras`: n_frames x 144-byte CameraUniform blobs, host memory) and its own heaviest-first tile order, dealt
+ * position-major so the heaviest tiles of every frame start first.  A frame that is 70 % empty cannot fill 8192 wave
+ * slots on its own; a batch can, and a rank holding 1/N of every frame still has n_frames/N frames of work per launch.
+ *   compact == 0 (nranks must be 1): `out` receives whole frames, [n_frames][height][width] pixels of the
+ *     backbuffer's format.
+ *   compact != 0: `out` receives this rank's tiles, [slot][frame][ts][ts] (slot j <-> position rank + j*nranks of
+ *     that frame's order), slot < *n_active_slots <= slot_capacity: a contiguous prefix, ready for one gather.
+ * *batch_id names the batch's tables for vk_untile_batch (the library holds the last 4).  VK_RENDER_COUNT is refused.
+ * Every frame is bitwise equal to the one vk_render produces for the same camera. */
+int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, uint32_t rank,
+                    uint32_t nranks, float dt_scale, uint32_t flags, void *out, int compact, uint32_t slot_capacity,
+                    uint32_t *batch_id, uint32_t *n_active_slots);
+/* Root side of a batch: gathered [nranks][n_slots][frame][ts][ts] -> out_frames [n_frames][height][width]. */
+int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32_t n_slots, void *out_frames);
+
+/* Device memory for hosts that have no other allocator (frame batches, gather buffers).  vk_device_free and
+ * vk_device_download synchronise the context's stream. */
+int vk_device_alloc(vk_ctx *ctx, size_t bytes, void **ptr);
+int vk_device_free(vk_ctx *ctx, void *ptr);
+int vk_device_download(vk_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
 /* ---- present + screenshot ---------------------------------------- */
 /* Context::render's present pass (src/context.rs:251-297, shaders/present.wgsl:23-35,111-119): bilinear
  * resample of the backbuffer to width x height (the window size), ACESFilm, linear_to_srgb, into the

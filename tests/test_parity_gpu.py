@@ -192,6 +192,69 @@ def test_partition_untile_equals_frame(V, O):
             ctx.close()
 
 
+def test_render_batch_equals_single_frames(V, O):
+    """vk_render_batch: B frames with B different cameras in ONE launch (whole frames at N = 1; per-rank compact
+    tiles + vk_untile_batch for N in {1, 2, 3, 8} emulated on this GPU) -- every frame bitwise equal to vk_render's,
+    on the cell layout with skipping (u8), on the staged bricks (f16) and in the compute twin."""
+    import torch
+
+    W, H, ts = 320, 200, 32
+    cams = [V.Camera(1.0 + 0.05 * k, 0.5 - 0.08 * k, 1.0 + 0.35 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(6)]
+    cams.insert(3, cams[2])  # a repeated camera inside the batch
+    cases = [("standin u8 / cells+skip", O.volume_standin_u8(64), None, V.LAYOUT_AUTO, V.MODE_NAIVE_TRILINEAR, V.OUT_RGBA16F, cams),
+             ("fog f16 / staged bricks", O.volume_fog_f16(48), None, V.LAYOUT_STAGED, V.MODE_NAIVE_TRILINEAR, V.OUT_RGBA32F, cams)]
+    for name, vol, vol2, lay, mode, fmt, cc in cases:
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=fmt)
+        try:
+            V.VolumeTexture(ctx, vol, vol2, layout=lay)
+            pipe = V.RaycastPipeline(mode, dt_scale=0.5)
+            tdt = torch.float16 if fmt == V.OUT_RGBA16F else torch.float32
+            singles = []
+            for c in cc:
+                ctx.set_camera_blob(c)
+                pipe.record(ctx)
+                singles.append(ctx.read_backbuffer().copy())
+            B = len(cc)
+            frames = torch.zeros((B, H, W, 4), dtype=tdt, device="cuda")
+            V.render_batch(ctx, pipe, cc, frames.data_ptr(), tile_size=ts)
+            ctx.sync()
+            got = frames.cpu().numpy()
+            for k in range(B):
+                assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), (name, "whole frames", k)
+            cap = V.partition_slots(W, H, ts, 1)
+            for nr in (1, 2, 3, 8):
+                gathered = None
+                for r in range(nr):
+                    buf = torch.zeros((cap, B, ts, ts, 4), dtype=tdt, device="cuda")
+                    bid, act = V.render_batch(ctx, pipe, cc, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
+                    if gathered is None:
+                        gathered = torch.zeros((nr, act, B, ts, ts, 4), dtype=tdt, device="cuda")
+                    ctx.sync()
+                    gathered[r] = buf[:act]  # what the rank would send: a contiguous prefix
+                frames.zero_()
+                V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
+                ctx.sync()
+                got = frames.cpu().numpy()
+                for k in range(B):
+                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), (name, "ranks", nr, k)
+        finally:
+            ctx.close()
+    # error behaviour: counters are per frame, whole frames need one rank, capacity is checked
+    ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture(ctx, O.volume_fog_u8(16))
+        buf = torch.zeros((4, 64, 64, 4), device="cuda")
+        cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
+        with pytest.raises(V.VokselisError):
+            V.render_batch(ctx, V.RaycastPipeline(flags=V.RENDER_COUNT), [cam], buf.data_ptr())
+        with pytest.raises(V.VokselisError):
+            V.render_batch(ctx, V.RaycastPipeline(), [cam], buf.data_ptr(), nranks=2)
+        with pytest.raises(V.VokselisError):
+            V.render_batch(ctx, V.RaycastPipeline(), [cam], buf.data_ptr(), compact=True, slot_capacity=0)
+    finally:
+        ctx.close()
+
+
 def test_tile_parallel_renderer_over_rccl_world1(V, O):
     """The production N > 1 driver (TileParallelRenderer: partition march, batched RCCL gather, un-tile) run
     as a world of one over RCCL: every delivered frame equals the single-launch frame bit for bit, across

@@ -1,0 +1,37 @@
+"""C2 frames per launch: one launch spanning B frames (vk_render_batch) against B single launches, and the
+slowest rank of N emulated on this GPU (compact tiles)."""
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import vokselis_amd as V
+
+W, H, TS = 1920, 1080, 64
+cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+blob = cam.get_proj_view_matrix()
+ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+V.VolumeTexture.generate_standin(ctx, (256,) * 3)
+ctx.update()
+pipe = V.RaycastPipeline(dt_scale=0.5)
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    ctx.sync(); ctx.timer_begin()
+    for _ in range(iters): fn()
+    ctx.timer_end()
+    return ctx.timer_elapsed_ms() / iters
+
+print(json.dumps({"single_launch_ms": round(timeit(lambda: pipe.record(ctx), 100), 4)}))
+cap = V.partition_slots(W, H, TS, 1)
+for B in (2, 4, 8, 16, 32):
+    frames = torch.empty((B, H, W, 4), dtype=torch.float16, device="cuda")
+    ms = timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, frames.data_ptr(), tile_size=TS))
+    print(json.dumps({"batch": B, "whole_frames_ms_per_frame": round(ms / B, 4)}))
+for B in (8, 16, 32):
+    for nr in (1, 2, 4, 8):
+        buf = torch.empty((cap, B, TS, TS, 4), dtype=torch.float16, device="cuda")
+        worst = 0.0
+        for r in range(nr):
+            ms = timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=r, nranks=nr, compact=True, slot_capacity=cap))
+            worst = max(worst, ms)
+        print(json.dumps({"batch": B, "nranks": nr, "slowest_rank_ms_per_frame": round(worst / B, 4)}))
+ctx.close()

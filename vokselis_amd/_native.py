@@ -49,6 +49,11 @@ SYMBOLS = {
     "vk_untile": (C.c_int, [_vp, _vp, _u32, _u32, _u32]),
     "vk_untile_epoch": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32]),
     "vk_partition_epoch": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "vk_render_batch": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _vp, C.c_int, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "vk_untile_batch": (C.c_int, [_vp, _u32, _vp, _u32, _vp]),
+    "vk_device_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "vk_device_free": (C.c_int, [_vp, _vp]),
+    "vk_device_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "vk_present": (C.c_int, [_vp, _u32, _u32, C.c_int]),
     "vk_capture_frame": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_readback": (C.c_int, [_vp, _vp, _sz]),

@@ -345,6 +345,21 @@ class RaycastPipeline:
                                                            self.flags, C.c_void_p(compact_ptr)))
 
 
+def render_batch(ctx: Context, pipe: RaycastPipeline, cameras, out_ptr: int, *, tile_size: int = 64, rank: int = 0, nranks: int = 1,
+                 compact: bool = False, slot_capacity: int = 0):
+    """vk_render_batch: len(cameras) frames (144-byte blobs) in one launch.  Returns (batch_id, active slots per rank)."""
+    blob = b"".join(cameras)
+    n = len(blob) // 144
+    bid, act = C.c_uint32(), C.c_uint32()
+    N.check(ctx.handle, N.lib().vk_render_batch(ctx.handle, pipe.mode, n, blob, tile_size, rank, nranks, pipe.dt_scale, pipe.flags,
+                                               C.c_void_p(out_ptr), 1 if compact else 0, slot_capacity, C.byref(bid), C.byref(act)))
+    return bid.value, act.value
+
+
+def untile_batch(ctx: Context, batch_id: int, gathered_ptr: int, n_slots: int, out_ptr: int):
+    N.check(ctx.handle, N.lib().vk_untile_batch(ctx.handle, batch_id, C.c_void_p(gathered_ptr), n_slots, C.c_void_p(out_ptr)))
+
+
 def partition_slots(width: int, height: int, tile_size: int, nranks: int) -> int:
     n = C.c_uint32()
     rc = N.lib().vk_partition_slots(width, height, tile_size, nranks, C.byref(n))

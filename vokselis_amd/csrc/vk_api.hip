@@ -72,6 +72,16 @@ struct vk_ctx {
     uint32_t ring_epoch[16] = {};    // the epoch (count of order changes) that filled the slot
     uint32_t order_epoch = 0;        // epoch of the current slot; epoch e lives in slot e % 16 while order_epoch - e < 16
 
+    // batched launches (vk_render_batch): per-batch tables {FrameDesc[B], order[B][n_tiles], pos[B][n_tiles]} in a small
+    // ring of device slots fed from pinned staging; a slot is rewritten only after the last kernel that read it
+    struct BatchSlot {
+        unsigned char *d = nullptr, *h = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0;
+    } batch[4];
+    uint32_t batch_seq = 0;
+
     // present targets (next row N1/N2)
     uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
     uint32_t present_w = 0, present_h = 0;
@@ -172,6 +182,7 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->trace) (void)hipFree(ctx->trace);
     if (ctx->d_ring) (void)hipFree(ctx->d_ring);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+    for (auto &b : ctx->batch) { if (b.d) (void)hipFree(b.d); if (b.h) (void)hipHostFree(b.h); if (b.ev) (void)hipEventDestroy(b.ev); }
     for (hipEvent_t e : ctx->ring_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -696,10 +707,10 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
 // Screen-space bounding rectangle of the unit cube (NAIVE mode): the 8 corners projected with
 // proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
 // Pixels outside [x0,x1) x [y0,y1) cannot hit the box.
-static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) {
+static void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]) {
     r[0] = 0; r[1] = 0; r[2] = (int32_t)ctx->width; r[3] = (int32_t)ctx->height;
     if (mode != VK_MODE_NAIVE_TRILINEAR) return;
-    const float *pv = ctx->camera + 4;
+    const float *pv = cam + 4;
     double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
     for (int c = 0; c < 8; c++) {
         const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
@@ -716,23 +727,18 @@ static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) {
     r[3] = (int32_t)std::min((double)ctx->height, std::ceil(y1) + 2.0);
 }
 
+static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) { cull_rect_cam(ctx, ctx->camera, mode, r); }
+
 // Tiles are dealt to the launch (and, at N > 1, to the ranks) heaviest first.  The frame is ~70 %
 // empty and a dense ray ends after 2 steps while a grazing one takes 513, so with ~10 working waves
 // per SIMD the kernel's tail is set by whichever heavy tiles start last; starting them first (and
 // round-robining them over ranks) shortens it.  The cost estimate is the nominal step count of a
 // 3x3 grid of rays per tile, from the same camera maths as the kernel, in double precision on the
 // host.  It is only a launch order: every tile is rendered by the same kernel whatever its rank.
-static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
-                             float dt_scale) {
+static void compute_tile_order(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                               std::vector<uint32_t> &order, std::vector<uint32_t> &order_pos, uint32_t &order_active) {
     const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
     const size_t n = (size_t)tx * ty;
-    std::vector<unsigned char> key(144 + 40);
-    std::memcpy(key.data(), ctx->camera, 144);
-    const uint32_t kk[10] = {(uint32_t)mode, (uint32_t)ox, (uint32_t)oy, rw, rh, ts, ctx->width, ctx->height, ctx->nx ^ (ctx->ny << 10) ^ (ctx->nz << 20), 0};
-    std::memcpy(key.data() + 144, kk, 40);
-    (void)dt_scale;
-    if (key == ctx->order_key && ctx->order.size() == n) return VK_OK;
-    const float *cam = ctx->camera;
     const double W = ctx->width, H = ctx->height;
     std::vector<double> cost(n, 0.0);
     auto mul = [&](const float *m, double x, double y, double z, double w, double o[4]) {
@@ -774,12 +780,12 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
                 }
             cost[(size_t)j * tx + i] = c;
         }
-    ctx->order.resize(n);
-    for (size_t t = 0; t < n; t++) ctx->order[t] = (uint32_t)t;
+    order.resize(n);
+    for (size_t t = 0; t < n; t++) order[t] = (uint32_t)t;
     // tiles that do not touch the cube's screen rectangle hold only clear-colour pixels: they sort last and
     // are "inactive" -- never marched, never gathered (the root clears them in vk_untile)
     int32_t cr[4];
-    cull_rect(ctx, mode, cr);
+    cull_rect_cam(ctx, cam, mode, cr);
     std::vector<unsigned char> active(n, 1);
     uint32_t n_active = 0;
     for (uint32_t j = 0; j < ty; j++)
@@ -789,17 +795,31 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
             active[(size_t)j * tx + i] = a;
             n_active += a;
         }
-    std::stable_sort(ctx->order.begin(), ctx->order.end(), [&](uint32_t a, uint32_t b) {
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         if (active[a] != active[b]) return active[a] > active[b];
         return cost[a] > cost[b];
     });
     // Position q goes to XCD q % 8 (rank q % N first, when the frame is partitioned): dealt straight, bin 0
     // would receive the heaviest tile of every round of 8.  Reverse every other round (snake) so the bins'
     // sums even out; the active tiles stay in front.
-    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(ctx->order.begin() + g, ctx->order.begin() + g + 8);
-    ctx->order_active = n_active;
-    ctx->order_pos.resize(n);
-    for (size_t q = 0; q < n; q++) ctx->order_pos[ctx->order[q]] = (uint32_t)q;
+    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(order.begin() + g, order.begin() + g + 8);
+    order_active = n_active;
+    order_pos.resize(n);
+    for (size_t q = 0; q < n; q++) order_pos[order[q]] = (uint32_t)q;
+}
+
+static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                             float dt_scale) {
+    const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
+    const size_t n = (size_t)tx * ty;
+    std::vector<unsigned char> key(144 + 40);
+    std::memcpy(key.data(), ctx->camera, 144);
+    const uint32_t kk[10] = {(uint32_t)mode, (uint32_t)ox, (uint32_t)oy, rw, rh, ts, ctx->width, ctx->height, ctx->nx ^ (ctx->ny << 10) ^ (ctx->nz << 20), 0};
+    std::memcpy(key.data() + 144, kk, 40);
+    (void)dt_scale;
+    if (key == ctx->order_key && ctx->order.size() == n) return VK_OK;
+    compute_tile_order(ctx, ctx->camera, mode, ox, oy, rw, rh, ts, ctx->order, ctx->order_pos, ctx->order_active);
+    const uint32_t n_active = ctx->order_active;
     constexpr int kOrderRing = 16;
     if (ctx->d_order_cap < n) {
         HIP_TRY(ctx, hipDeviceSynchronize());  // a larger frame shape: rebuild the ring (rare)
@@ -844,13 +864,13 @@ static int order_wait(vk_ctx *ctx) {
     return VK_OK;
 }
 
-static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
-                         uint32_t rank, uint32_t nranks, float dt_scale, uint32_t flags, void *compact_out) {
+// Argument and state checks shared by every render entry point; `cam` is the 144-byte camera the frame uses.
+static int check_render(vk_ctx *ctx, int mode, const float *cam, float dt_scale, uint32_t ts, uint32_t rank, uint32_t nranks) {
     if (!ctx) return VK_ERR_INVALID;
     if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "unknown mode");
     if (ctx->format < 0 && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "render: no volume uploaded");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "render: no backbuffer (vk_backbuffer_resize)");
-    if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "render: no camera (vk_set_camera)");
+    if (!cam) return fail(ctx, VK_ERR_INVALID, "render: no camera (vk_set_camera)");
     // PROCEDURAL shares the compute twin's ray, box and step: geometry helpers treat it as that mode
     const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
     if (mode == VK_MODE_NAIVE_TRILINEAR && ctx->format == VK_FMT_RGBA16F_PAIR)
@@ -858,13 +878,12 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     if (mode == VK_MODE_COMPUTE_NEAREST && ctx->format != VK_FMT_RGBA16F_PAIR)
         return fail(ctx, VK_ERR_INVALID, "COMPUTE_NEAREST needs an RGBA16F_PAIR volume");
     if (!(dt_scale > 0.0f) || !std::isfinite(dt_scale)) return fail(ctx, VK_ERR_INVALID, "dt_scale must be finite and > 0");
-    if (rw == 0 || rh == 0) return VK_OK;  // empty tile
     if (ts == 0 || (ts & 7u) || ts > 1024) return fail(ctx, VK_ERR_INVALID, "tile size must be a multiple of 8 in [8, 1024]");
     if (nranks == 0 || rank >= nranks) return fail(ctx, VK_ERR_INVALID, "rank/nranks");
     // Loop-termination guard (the reference would hang the GPU on a dt that no longer advances t):
     // t <= |eye - box| + box diagonal; require dt >= 8 ulp(t_max).
     {
-        const float *e = ctx->camera;
+        const float *e = cam;
         float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
         if (geo_mode == VK_MODE_COMPUTE_NEAREST) reach += 200.0f;  // near-plane point of a far=100 frustum
         float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
@@ -872,67 +891,19 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         float ulp = std::nextafter(reach, 2.0f * reach) - reach;
         if (!(dt_min >= 8.0f * ulp)) return fail(ctx, VK_ERR_UNSUPPORTED, "dt too small against the camera distance: the march would not advance");
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return VK_OK;
+}
+
+// Launch the march kernel of the context's volume for a filled LaunchDesc (one frame or a batch).
+// `reach_cam`: the camera whose distance decides whether the unclamped fast path is safe (the farthest of a batch).
+static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L, uint32_t flags, const float *reach_cam) {
     const bool count = (flags & VK_RENDER_COUNT) != 0;
-    if (count && !ctx->steps) {
-        HIP_TRY(ctx, hipMalloc(&ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->steps, 0, (size_t)ctx->width * ctx->height * sizeof(uint32_t), ctx->stream));
-    }
-    LaunchDesc L{};
-    L.eye[0] = ctx->camera[0]; L.eye[1] = ctx->camera[1]; L.eye[2] = ctx->camera[2]; L.eye[3] = ctx->camera[3];
-    std::memcpy(L.inv_proj, ctx->camera + 20, 64);
-    L.W = ctx->width; L.H = ctx->height;
-    L.ox = ox; L.oy = oy; L.rw = rw; L.rh = rh;
-    L.ts = ts;
-    L.tiles_x = (rw + ts - 1) / ts;
-    L.tiles_y = (rh + ts - 1) / ts;
-    {
-        int32_t cr[4];
-        cull_rect(ctx, geo_mode, cr);
-        L.cull_x0 = cr[0]; L.cull_y0 = cr[1]; L.cull_x1 = cr[2]; L.cull_y1 = cr[3];
-    }
-    L.rank = rank; L.nranks = nranks;
-    {
-        int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts, dt_scale);
-        if (orc) return orc;
-        orc = order_wait(ctx);
-        if (orc) return orc;
-        L.tile_order = ctx->d_order;
-    }
-    // a partition (compact output) covers only the active tiles; a plain render covers the whole region
-    const uint64_t tiles = compact_out ? (uint64_t)ctx->order_active : (uint64_t)L.tiles_x * L.tiles_y;
-    const uint64_t slots = (tiles + nranks - 1) / nranks;
-    L.n_tiles_launch = (uint32_t)tiles;
-    if (tiles == 0) return VK_OK;
-    const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
-    const uint64_t n_blocks = slots * per_tile;
-    if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large");
-    L.n_blocks = (uint32_t)n_blocks;
-    L.compact = compact_out ? 1u : 0u;
-    L.dt_scale = dt_scale;
-    L.out = compact_out ? compact_out : ctx->backbuffer;
-    L.steps = count ? ctx->steps : nullptr;
-    L.counters = count ? ctx->counters : nullptr;
-    L.trace = nullptr;
-    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u);
-    if (count && ctx->want_trace) {
-        if (ctx->trace_blocks < n_blocks) {
-            if (ctx->trace) (void)hipFree(ctx->trace);
-            ctx->trace = nullptr; ctx->trace_blocks = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 4 * sizeof(unsigned long long)));
-            ctx->trace_blocks = n_blocks;
-        }
-        // start = +inf (atomicMin), end = 0 (atomicMax): fill {0xff.., 0} pairs
-        std::vector<unsigned long long> init(n_blocks * 4, 0ull);
-        for (uint64_t i = 0; i < n_blocks; i++) init[4 * i] = ~0ull;
-        HIP_TRY(ctx, hipMemcpy(ctx->trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-        L.trace = ctx->trace;
-    }
     VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
     V.lut = ctx->lut;  // the no-skip variants take the byte-offset copy (set where the variant is chosen)
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
+    const uint64_t n_blocks = L.n_blocks;
     const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
     if (mode == VK_MODE_PROCEDURAL) {
         float time = 0.0f;
@@ -975,7 +946,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         // (|p error| <= ~64 ulp(reach) << 0.5/n).
         bool safe = true;
         {
-            const float *e = ctx->camera;
+            const float *e = reach_cam;
             float reach = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 4.0f;
             float nmax = (float)std::max(ctx->nx, std::max(ctx->ny, ctx->nz));
             float ulp = std::nextafter(reach, 2.0f * reach) - reach;
@@ -997,6 +968,74 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     }
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
+}
+
+static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                         uint32_t rank, uint32_t nranks, float dt_scale, uint32_t flags, void *compact_out) {
+    if (!ctx) return VK_ERR_INVALID;
+    int crc = check_render(ctx, mode, ctx->have_camera ? ctx->camera : nullptr, dt_scale, ts, rank, nranks);
+    if (crc) return crc;
+    const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
+    if (rw == 0 || rh == 0) return VK_OK;  // empty tile
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool count = (flags & VK_RENDER_COUNT) != 0;
+    if (count && !ctx->steps) {
+        HIP_TRY(ctx, hipMalloc(&ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->steps, 0, (size_t)ctx->width * ctx->height * sizeof(uint32_t), ctx->stream));
+    }
+    LaunchDesc L{};
+    L.eye[0] = ctx->camera[0]; L.eye[1] = ctx->camera[1]; L.eye[2] = ctx->camera[2]; L.eye[3] = ctx->camera[3];
+    std::memcpy(L.inv_proj, ctx->camera + 20, 64);
+    L.W = ctx->width; L.H = ctx->height;
+    L.ox = ox; L.oy = oy; L.rw = rw; L.rh = rh;
+    L.ts = ts;
+    L.tiles_x = (rw + ts - 1) / ts;
+    L.tiles_y = (rh + ts - 1) / ts;
+    {
+        int32_t cr[4];
+        cull_rect(ctx, geo_mode, cr);
+        L.cull_x0 = cr[0]; L.cull_y0 = cr[1]; L.cull_x1 = cr[2]; L.cull_y1 = cr[3];
+    }
+    L.rank = rank; L.nranks = nranks;
+    {
+        int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts, dt_scale);
+        if (orc) return orc;
+        orc = order_wait(ctx);
+        if (orc) return orc;
+        L.tile_order = ctx->d_order;
+    }
+    // a partition (compact output) covers only the active tiles; a plain render covers the whole region
+    const uint64_t tiles = compact_out ? (uint64_t)ctx->order_active : (uint64_t)L.tiles_x * L.tiles_y;
+    const uint64_t slots = (tiles + nranks - 1) / nranks;
+    L.n_tiles_launch = (uint32_t)tiles;
+    if (tiles == 0) return VK_OK;
+    const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
+    const uint64_t n_blocks = slots * per_tile;
+    if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large");
+    L.n_blocks = (uint32_t)n_blocks;
+    L.compact = compact_out ? 1u : 0u;
+    L.dt_scale = dt_scale;
+    L.out = compact_out ? compact_out : ctx->backbuffer;
+    L.steps = count ? ctx->steps : nullptr;
+    L.counters = count ? ctx->counters : nullptr;
+    L.trace = nullptr;
+    L.frames = nullptr;
+    L.n_frames = 1;
+    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u);
+    if (count && ctx->want_trace) {
+        if (ctx->trace_blocks < n_blocks) {
+            if (ctx->trace) (void)hipFree(ctx->trace);
+            ctx->trace = nullptr; ctx->trace_blocks = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 4 * sizeof(unsigned long long)));
+            ctx->trace_blocks = n_blocks;
+        }
+        // start = +inf (atomicMin), end = 0 (atomicMax): fill {0xff.., 0} pairs
+        std::vector<unsigned long long> init(n_blocks * 4, 0ull);
+        for (uint64_t i = 0; i < n_blocks; i++) init[4 * i] = ~0ull;
+        HIP_TRY(ctx, hipMemcpy(ctx->trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        L.trace = ctx->trace;
+    }
+    return dispatch_march(ctx, mode, L, flags, ctx->camera);
 }
 
 extern "C" {
@@ -1122,6 +1161,143 @@ int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint3
 int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch) {
     if (!ctx || !epoch) return VK_ERR_INVALID;
     *epoch = ctx->order_epoch;
+    return VK_OK;
+}
+
+
+// ---- batched launches -----------------------------------------------------------------------------
+
+int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                    float dt_scale, uint32_t flags, void *out, int compact, uint32_t slot_capacity, uint32_t *batch_id, uint32_t *n_active_slots) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!cameras || !out) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: NULL argument");
+    if (n_frames == 0 || n_frames > 256) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: 1..256 frames per batch");
+    if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: the step counters describe one frame; count with vk_render");
+    if (!compact && nranks != 1) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: whole frames need nranks == 1; a rank's share is compact");
+    const float *cams = reinterpret_cast<const float *>(cameras);
+    for (uint32_t i = 0; i < n_frames * 36u; i++)
+        if (!std::isfinite(cams[i])) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: camera blob has non-finite entries");
+    const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
+    const float *far_cam = cams;  // the camera farthest from the volume decides the safe-path test
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const float *c = cams + 36 * f;
+        int crc = check_render(ctx, mode, c, dt_scale, tile_size, rank, nranks);
+        if (crc) return crc;
+        if (c[0] * c[0] + c[1] * c[1] + c[2] * c[2] > far_cam[0] * far_cam[0] + far_cam[1] * far_cam[1] + far_cam[2] * far_cam[2]) far_cam = c;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t ts = tile_size, tx = (ctx->width + ts - 1) / ts, ty = (ctx->height + ts - 1) / ts;
+    const size_t n_tiles = (size_t)tx * ty;
+    const size_t bytes = (size_t)n_frames * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t));
+    vk_ctx::BatchSlot &B = ctx->batch[ctx->batch_seq % 4u];
+    if (B.ev) HIP_TRY(ctx, hipEventSynchronize(B.ev));  // the launches of four batches ago have long finished
+    else HIP_TRY(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+    if (B.cap < bytes) {
+        if (B.d) (void)hipFree(B.d);
+        if (B.h) (void)hipHostFree(B.h);
+        B.d = B.h = nullptr; B.cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&B.d, bytes));
+        HIP_TRY(ctx, hipHostMalloc((void **)&B.h, bytes));
+        B.cap = bytes;
+    }
+    FrameDesc *fd = reinterpret_cast<FrameDesc *>(B.h);
+    uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
+    uint32_t *h_pos = h_order + (size_t)n_frames * n_tiles;
+    uint32_t max_active = 0;
+    std::vector<uint32_t> order, pos;
+    uint32_t n_active = 0;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const float *c = cams + 36 * f;
+        const bool same = f > 0 && std::memcmp(c, c - 36, 144) == 0;  // a still camera costs one order per batch
+        if (!same) compute_tile_order(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, order, pos, n_active);
+        std::memcpy(fd[f].eye, c, 16);
+        std::memcpy(fd[f].inv_proj, c + 20, 64);
+        int32_t cr[4];
+        cull_rect_cam(ctx, c, geo_mode, cr);
+        fd[f].cull_x0 = cr[0]; fd[f].cull_y0 = cr[1]; fd[f].cull_x1 = cr[2]; fd[f].cull_y1 = cr[3];
+        fd[f].order_off = (uint32_t)(f * n_tiles);
+        // whole frames cover every tile (the kernel clears the inactive ones); a rank's share only the active ones
+        fd[f].n_active = compact ? n_active : (uint32_t)n_tiles;
+        fd[f].pad[0] = n_active; fd[f].pad[1] = 0;
+        std::memcpy(h_order + f * n_tiles, order.data(), n_tiles * sizeof(uint32_t));
+        std::memcpy(h_pos + f * n_tiles, pos.data(), n_tiles * sizeof(uint32_t));
+        max_active = std::max(max_active, n_active);
+    }
+    const uint32_t slots_active = (max_active + nranks - 1) / nranks;
+    if (n_active_slots) *n_active_slots = slots_active;
+    const uint64_t slots = compact ? (uint64_t)slots_active : (uint64_t)n_tiles;
+    if (compact && slots_active > slot_capacity) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: slot_capacity smaller than the active slots of this batch");
+    HIP_TRY(ctx, hipMemcpyAsync(B.d, B.h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    B.id = ++ctx->batch_seq;
+    B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active;
+    if (batch_id) *batch_id = B.id;
+    if (slots == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
+    LaunchDesc L{};
+    L.W = ctx->width; L.H = ctx->height;
+    L.ox = 0; L.oy = 0; L.rw = ctx->width; L.rh = ctx->height;
+    L.ts = ts; L.tiles_x = tx; L.tiles_y = ty;
+    L.rank = rank; L.nranks = nranks;
+    L.tile_order = reinterpret_cast<const uint32_t *>(B.d + (size_t)n_frames * sizeof(FrameDesc));
+    L.n_tiles_launch = 0;
+    const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
+    const uint64_t n_blocks = slots * n_frames * per_tile;
+    if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large: fewer frames per batch");
+    L.n_blocks = (uint32_t)n_blocks;
+    L.compact = compact ? 1u : 0u;
+    L.dt_scale = dt_scale;
+    L.out = out;
+    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = 0;
+    L.frames = reinterpret_cast<const FrameDesc *>(B.d);
+    L.n_frames = n_frames;
+    const int rc = dispatch_march(ctx, mode, L, flags, far_cam);
+    HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream));
+    return rc;
+}
+
+int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32_t n_slots, void *out_frames) {
+    if (!ctx || !gathered || !out_frames) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: NULL argument");
+    vk_ctx::BatchSlot *B = nullptr;
+    for (auto &b : ctx->batch) if (b.id == batch_id && b.id != 0) B = &b;
+    if (!B) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: that batch is no longer held (more than 3 batches ago)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t tx = (ctx->width + B->ts - 1) / B->ts;
+    const uint64_t n = (uint64_t)ctx->width * ctx->height * B->n_frames;
+    if ((n + 255) / 256 >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile_batch: too many pixels for one launch");
+    const FrameDesc *frames = reinterpret_cast<const FrameDesc *>(B->d);
+    const uint32_t *pos = reinterpret_cast<const uint32_t *>(B->d + (size_t)B->n_frames * sizeof(FrameDesc)) + (size_t)B->n_frames * B->n_tiles;
+    // FrameDesc::n_active of a compact batch is the frame's active tile count (what the gather carried)
+    if (ctx->out_format == VK_OUT_RGBA16F)
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames);
+    else
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(B->ev, ctx->stream));
+    return VK_OK;
+}
+
+// Device buffers for hosts without another allocator (the C++ host, a plain C consumer): frame batches, gather buffers.
+int vk_device_alloc(vk_ctx *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr || bytes == 0) return fail(ctx, VK_ERR_INVALID, "vk_device_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *ptr = nullptr;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? VK_ERR_OOM : VK_ERR_HIP, std::string("vk_device_alloc: ") + hipGetErrorString(e));
+    return VK_OK;
+}
+
+int vk_device_free(vk_ctx *ctx, void *ptr) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ptr));
+    return VK_OK;
+}
+
+int vk_device_download(vk_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+    if (!ctx || !dst_host || !src_device) return fail(ctx, VK_ERR_INVALID, "vk_device_download: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VK_OK;
 }
 

@@ -64,6 +64,17 @@ struct VolumeDesc {
     uint32_t sh_x, sh_y, sh_z;
 };
 
+// One frame of a batched launch (vk_render_batch): its camera, its cull rectangle and its own tile order.
+struct FrameDesc {
+    float eye[4];
+    float inv_proj[16];  // column-major
+    int32_t cull_x0, cull_y0, cull_x1, cull_y1;
+    uint32_t order_off;  // offset of this frame's order table in LaunchDesc::tile_order
+    uint32_t n_active;   // leading positions of that order this launch covers
+    uint32_t pad[2];
+};
+static_assert(sizeof(FrameDesc) == 112, "FrameDesc is read with scalar loads: keep it a multiple of 16 bytes");
+
 struct LaunchDesc {
     float eye[4];
     float inv_proj[16];  // column-major
@@ -84,6 +95,12 @@ struct LaunchDesc {
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
     uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
+    // batched launch: the grid spans n_frames frames, position-major (slot 0 of every frame, then slot 1, ...), so
+    // the heaviest tiles of all frames start first.  frames == nullptr: one frame, described by the fields above.
+    // Compact output of a batch is position-major too, [slot][frame][ts][ts], so that the tiles a rank has to send
+    // (the leading active slots of every frame) are one contiguous prefix; full frames are [frame][H][W].
+    const FrameDesc *frames;
+    uint32_t n_frames;
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------
@@ -110,14 +127,56 @@ struct PixelMap {
     size_t out_index;  // pixel index into the output
 };
 
-__device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, uint32_t lb, uint32_t lane) {
+// The frame a wave belongs to: camera, cull rectangle, order table.  Wave-uniform (scalar loads).
+struct FrameView {
+    float eye[4];
+    float inv_proj[16];
+    int32_t cull_x0, cull_y0, cull_x1, cull_y1;
+    const uint32_t *order;
+    uint32_t n_tiles_launch;
+    uint32_t frame;
+    uint32_t lb;  // the wave's logical block inside its frame
+};
+
+__device__ __forceinline__ FrameView frame_view(const LaunchDesc &L, uint32_t lb) {
+    FrameView f;
+    if (L.frames) {
+        const uint32_t sps = L.ts >> 3, per_tile = sps * sps;
+        const uint32_t g = lb / per_tile, sub = lb - g * per_tile;  // g: (slot, frame) pairs, frame fastest
+        const uint32_t slot = g / L.n_frames;
+        f.frame = g - slot * L.n_frames;
+        f.lb = slot * per_tile + sub;
+        const FrameDesc &d = L.frames[f.frame];
+#pragma unroll
+        for (int i = 0; i < 4; i++) f.eye[i] = d.eye[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) f.inv_proj[i] = d.inv_proj[i];
+        f.cull_x0 = d.cull_x0; f.cull_y0 = d.cull_y0; f.cull_x1 = d.cull_x1; f.cull_y1 = d.cull_y1;
+        f.order = L.tile_order + d.order_off;
+        f.n_tiles_launch = d.n_active;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) f.eye[i] = L.eye[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) f.inv_proj[i] = L.inv_proj[i];
+        f.cull_x0 = L.cull_x0; f.cull_y0 = L.cull_y0; f.cull_x1 = L.cull_x1; f.cull_y1 = L.cull_y1;
+        f.order = L.tile_order;
+        f.n_tiles_launch = L.n_tiles_launch;
+        f.frame = 0;
+        f.lb = lb;
+    }
+    return f;
+}
+
+__device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameView &fv, uint32_t lane) {
     PixelMap m;
+    const uint32_t lb = fv.lb;
     uint32_t sps = L.ts >> 3;              // 8x8 blocks per tile edge
     uint32_t per_tile = sps * sps;
     uint32_t slot = lb / per_tile, sub = lb - slot * per_tile;
     uint32_t pos = L.rank + slot * L.nranks;  // position in the heaviest-first order
     const uint32_t n_tiles = L.tiles_x * L.tiles_y;
-    uint32_t tile = pos < L.n_tiles_launch ? L.tile_order[pos] : n_tiles;
+    uint32_t tile = pos < fv.n_tiles_launch ? fv.order[pos] : n_tiles;
     uint32_t tty = tile / L.tiles_x, ttx = tile - tty * L.tiles_x;
     uint32_t sy = sub / sps, sx = sub - sy * sps;
     uint32_t lx = sx * 8 + (lane & 7u), ly = sy * 8 + (lane >> 3);  // inside the tile
@@ -126,7 +185,9 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, uint32_t lb, 
     m.y = L.oy + (int32_t)ry;
     m.valid = (tile < n_tiles) && rx < L.rw && ry < L.rh && m.x >= 0 && m.y >= 0 &&
               m.x < (int32_t)L.W && m.y < (int32_t)L.H;
-    m.out_index = L.compact ? ((size_t)slot * L.ts + ly) * L.ts + lx : (size_t)m.y * L.W + (size_t)m.x;
+    const uint32_t nf = L.frames ? L.n_frames : 1u;
+    m.out_index = L.compact ? (((size_t)slot * nf + fv.frame) * L.ts + ly) * L.ts + lx
+                            : ((size_t)fv.frame * L.H + (size_t)m.y) * L.W + (size_t)m.x;
     return m;
 }
 
@@ -762,12 +823,13 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     const uint32_t lane = threadIdx.x;
     unsigned long long t_start = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
-    const PixelMap pm = map_pixel(L, lb, lane);
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
     {
         // Screen-space cull (wave-uniform): an 8x8 block wholly outside the projected cube's bounding
         // rectangle (host-computed, padded) holds only misses: clear colour, no ray set-up.
         const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
-        if (bx0 + 8 <= L.cull_x0 || bx0 >= L.cull_x1 || by0 + 8 <= L.cull_y0 || by0 >= L.cull_y1) {
+        if (bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {
             if (!pm.valid) return;
             store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
@@ -787,8 +849,8 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     float ndcx = (2.0f * fxp) / (float)L.W - 1.0f;
     float ndcy = 1.0f - (2.0f * fyp) / (float)L.H;
     float q[4];
-    mat4_mul_vec4(L.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
-    const float eye[3] = {L.eye[0], L.eye[1], L.eye[2]};
+    mat4_mul_vec4(fv.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
+    const float eye[3] = {fv.eye[0], fv.eye[1], fv.eye[2]};
     float dir[3] = {q[0] / q[3] - eye[0], q[1] / q[3] - eye[1], q[2] / q[3] - eye[2]};
     normalize3(dir[0], dir[1], dir[2]);
 
@@ -905,7 +967,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
     const uint32_t lane = threadIdx.x;
-    const PixelMap pm = map_pixel(L, lb, lane);
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
     extern __shared__ uint32_t pair_lut[];
     {
         const uint32_t n4 = pair_lut_entries(V.nx, V.ny, V.nz) >> 2;
@@ -922,8 +985,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
     float scy = 2.0f * (float)pm.y / dimy - 1.0f;
     scy = scy * -aspect_ratio;
     float vp[4], vt[4];
-    mat4_mul_vec4(L.inv_proj, scx, scy, 0.0f, 1.0f, vp);
-    mat4_mul_vec4(L.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
     const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
     float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
     normalize3(dir[0], dir[1], dir[2]);
@@ -1004,7 +1067,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
     const uint32_t lane = threadIdx.x;
-    const PixelMap pm = map_pixel(L, lb, lane);
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
     if (!pm.valid) return;
 
     // render(): raycast_compute.wgsl:99-116 -- no half-pixel offset, y scaled by -H/W
@@ -1014,8 +1078,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
     float scy = 2.0f * (float)pm.y / dimy - 1.0f;
     scy = scy * -aspect_ratio;
     float vp[4], vt[4];
-    mat4_mul_vec4(L.inv_proj, scx, scy, 0.0f, 1.0f, vp);
-    mat4_mul_vec4(L.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
     const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
     float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
     normalize3(dir[0], dir[1], dir[2]);
@@ -1388,7 +1452,8 @@ template <int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDesc L, float time) {
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
-    const PixelMap pm = map_pixel(L, lb, threadIdx.x);
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, threadIdx.x);
     if (!pm.valid) return;
     float dimx = (float)L.W, dimy = (float)L.H;
     float aspect_ratio = dimy / dimx;
@@ -1396,8 +1461,8 @@ __global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDes
     float scy = 2.0f * (float)pm.y / dimy - 1.0f;
     scy = scy * -aspect_ratio;
     float vp[4], vt[4];
-    mat4_mul_vec4(L.inv_proj, scx, scy, 0.0f, 1.0f, vp);
-    mat4_mul_vec4(L.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
     const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
     float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
     normalize3(dir[0], dir[1], dir[2]);
@@ -1508,6 +1573,29 @@ __global__ __launch_bounds__(256) void untile_kernel(const void *__restrict__ ga
     }
     uint32_t rank = pos % nranks, slot = pos / nranks;
     size_t src = (((size_t)rank * n_slots + slot) * ts + (y % ts)) * ts + (x % ts);
+    if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];
+    else reinterpret_cast<uint2 *>(out)[id] = reinterpret_cast<const uint2 *>(gathered)[src];
+}
+
+// Root side of a batched multi-GPU launch: gathered [nranks][slot][frame][ts][ts] (slot < n_slots) -> frames [B][H][W].
+// tables: per frame, the inverse order (tile id -> position) at tables[pos_off + frame * n_tiles].
+template <int OUT>
+__global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restrict__ gathered, void *__restrict__ out, uint32_t W, uint32_t H, uint32_t ts,
+                                                           uint32_t tiles_x, uint32_t n_tiles, uint32_t nranks, uint32_t n_slots, uint32_t n_frames,
+                                                           const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames) {
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t npx = (uint64_t)W * H;
+    if (id >= npx * n_frames) return;
+    const uint32_t frame = (uint32_t)(id / npx);
+    const uint32_t px = (uint32_t)(id - (uint64_t)frame * npx);
+    const uint32_t x = px % W, y = px / W;
+    const uint32_t pos = tile_pos[(size_t)frame * n_tiles + (y / ts) * tiles_x + (x / ts)];
+    if (pos >= frames[frame].n_active) {  // outside the cube's screen rectangle: never marched, never gathered
+        store_pixel<OUT>(out, id, 0.0f, 0.0f, 0.0f, 1.0f);
+        return;
+    }
+    const uint32_t rank = pos % nranks, slot = pos / nranks;
+    const size_t src = ((((size_t)rank * n_slots + slot) * n_frames + frame) * ts + (y % ts)) * ts + (x % ts);
     if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];
     else reinterpret_cast<uint2 *>(out)[id] = reinterpret_cast<const uint2 *>(gathered)[src];
 }

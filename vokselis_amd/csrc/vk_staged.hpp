@@ -358,10 +358,11 @@ __global__ __launch_bounds__(64) void raymarch_staged_kernel(const LaunchDesc L,
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
-    const PixelMap pm = map_pixel(L, lb, lane);
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
     {
         const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
-        if (bx0 + 8 <= L.cull_x0 || bx0 >= L.cull_x1 || by0 + 8 <= L.cull_y0 || by0 >= L.cull_y1) {  // wave-uniform
+        if (bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {  // wave-uniform
             if (!pm.valid) return;
             store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(64) void raymarch_staged_kernel(const LaunchDesc L,
         float ndcx = (2.0f * fxp) / (float)L.W - 1.0f;
         float ndcy = 1.0f - (2.0f * fyp) / (float)L.H;
         float q[4];
-        mat4_mul_vec4(L.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
-        const float eye[3] = {L.eye[0], L.eye[1], L.eye[2]};
+        mat4_mul_vec4(fv.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
+        const float eye[3] = {fv.eye[0], fv.eye[1], fv.eye[2]};
         float dir[3] = {q[0] / q[3] - eye[0], q[1] / q[3] - eye[1], q[2] / q[3] - eye[2]};
         normalize3(dir[0], dir[1], dir[2]);
         float t0, t1;
