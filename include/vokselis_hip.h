@@ -193,6 +193,36 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
 /* Root side of a batch: gathered [nranks][n_slots][frame][ts][ts] -> out_frames [n_frames][height][width]. */
 int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32_t n_slots, void *out_frames);
 
+/* ---- multi-GPU: the framebuffer's tiles over the node's GPUs, RCCL over xGMI ------------- */
+/* Generalises the reference's tile loop (examples/xor/main.rs:235-254: one dispatch per 256x256 tile) to one GPU per
+ * share of the tiles.  The volume is replicated (upload it on every context); there is no reduction, only the
+ * gather of finished tiles to the root.  RCCL is loaded on first use.
+ *
+ * (a) one process per GPU (MPI / torchrun style): rank 0 makes an id, the host ships its 128 bytes to the peers,
+ *     every rank joins; then per batch vk_render_batch(compact) -> vk_gather_tiles -> (root) vk_untile_batch. */
+#define VK_COMM_ID_BYTES 128
+int vk_comm_unique_id(void *id128);
+int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks);
+int vk_comm_destroy(vk_ctx *ctx);
+int vk_comm_info(vk_ctx *ctx, int *rank, int *nranks);
+/* Every rank contributes n_pixels pixels (backbuffer format) from `send`; the root receives [nranks][n_pixels] in
+ * `recv` (ignored elsewhere).  One grouped send/recv, asynchronous, on `hip_stream` (NULL: the context's stream; a
+ * separate stream lets the gather of one batch overlap the march of the next -- the caller orders the two). */
+int vk_gather_tiles(vk_ctx *ctx, const void *send, void *recv, size_t n_pixels, int root, void *hip_stream);
+/* (b) one process for the node: a group owns one context per GPU (ncclCommInitAll).  Upload the volume and size the
+ *     backbuffer on every member (vk_group_ctx), then vk_group_render marches, gathers and un-tiles n_frames frames
+ *     into out_frames ([n_frames][height][width], device memory of GPU ordinals[0]).  Asynchronous; vk_group_sync
+ *     waits for every member. */
+typedef struct vk_group vk_group;
+int vk_group_create(int n, const int *ordinals, vk_group **out);
+int vk_group_destroy(vk_group *g);
+int vk_group_size(vk_group *g);
+vk_ctx *vk_group_ctx(vk_group *g, int i);
+int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, float dt_scale,
+                    uint32_t flags, void *out_frames);
+int vk_group_sync(vk_group *g);
+const char *vk_group_last_error(vk_group *g);
+
 /* Device memory for hosts that have no other allocator (frame batches, gather buffers).  vk_device_free and
  * vk_device_download synchronise the context's stream. */
 int vk_device_alloc(vk_ctx *ctx, size_t bytes, void **ptr);

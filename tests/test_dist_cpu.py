@@ -1,6 +1,7 @@
 """CPU suite, part 3: the N > 1 path on the gloo backend, world_size 2 (one process per rank).
-Each rank fills its compact tile buffer from the oracle's frame (test double for the HIP march),
-the production FrameGather moves it, and the root un-tiles: the result must be the oracle frame."""
+Each rank fills its compact batch buffer ([slot][frame][ts][ts], the layout vk_render_batch writes) from the
+oracle's frames (test double for the HIP march), the production TorchTileGather moves the active prefix, and the
+root un-tiles with the numpy statement of vk_untile_batch: the result must be the oracle frames."""
 import os
 import socket
 
@@ -28,31 +29,25 @@ def _worker(rank, world, port, W, H, ts, q):
     try:
         vol = O.volume_standin_u8(32)
         cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-        # two frames per collective call, two batches in flight through the two buffer sets
-        B = 2
-        dts = (1.0, 0.5, 0.75)  # 3 frames: one full batch + one partial (flushed with count = 1)
-        fg = D.FrameGather(W, H, ts, torch.float32, torch.device("cpu"), root=0, batch=B)
+        dts = (1.0, 0.5, 0.75)  # a batch of three frames
+        B = len(dts)
         tx, _ = D.tiles_xy(W, H, ts)
-        compact, gathered = fg.buffers()
-        works = []
-        for k, dt in enumerate(dts):
-            g, b = divmod(k, B)
-            buf = compact[g % 2][b].numpy()
+        cap = D.n_slots(W, H, ts, world)
+        send = torch.zeros((cap, B, ts, ts, 4), dtype=torch.float32)
+        for b, dt in enumerate(dts):
             for j, t in enumerate(D.local_tiles(W, H, ts, rank, world)):
                 x0, y0 = (t % tx) * ts, (t // tx) * ts
                 full, _, _ = O.render(cam, vol, W, H, dt_scale=dt, tile=(x0, y0, ts, ts), want_counts=False)
                 tile = full[y0:y0 + ts, x0:x0 + ts]
-                buf[j, :tile.shape[0], :tile.shape[1]] = tile
-            if b == B - 1 or k == len(dts) - 1:
-                works.append(fg.start(g % 2, None, b + 1))
-        for w in works:
-            w.wait()
+                send[j, b, :tile.shape[0], :tile.shape[1]] = torch.from_numpy(np.ascontiguousarray(tile))
+        tg = D.TorchTileGather(root=0)
+        recv = torch.zeros((world, cap, B, ts, ts, 4), dtype=torch.float32) if rank == 0 else None
+        tg.gather(send, recv)
         if rank == 0:
-            for k, dt in enumerate(dts):
-                g, b = divmod(k, B)
-                frame = D.untile_reference(gathered[g % 2][:, b].numpy(), W, H, ts)
+            frames = D.untile_batch_reference(recv.numpy(), W, H, ts)
+            for b, dt in enumerate(dts):
                 ref, _, _ = O.render(cam, vol, W, H, dt_scale=dt, want_counts=False)
-                q.put((k, float(np.abs(frame - ref).max()), bool((frame == ref).all())))
+                q.put((b, float(np.abs(frames[b] - ref).max()), bool((frames[b] == ref).all())))
     finally:
         dist.destroy_process_group()
 
@@ -70,4 +65,4 @@ def test_gloo_world2_tile_gather(W, H, ts):
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(3))
     assert [g[0] for g in got] == [0, 1, 2]
-    assert all(g[2] for g in got), got  # bit-identical to the single-process oracle frame
+    assert all(g[2] for g in got), got  # bit-identical to the single-process oracle frames

@@ -255,121 +255,62 @@ def test_render_batch_equals_single_frames(V, O):
         ctx.close()
 
 
-def test_tile_parallel_renderer_over_rccl_world1(V, O):
-    """The production N > 1 driver (TileParallelRenderer: partition march, batched RCCL gather, un-tile) run
-    as a world of one over RCCL: every delivered frame equals the single-launch frame bit for bit, across
-    full batches, a partial batch closed by flush(), and a camera change in the middle of a batch."""
-    import os
+def _orbit_cameras(V, n, aspect):
+    return [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), aspect).get_proj_view_matrix() for k in range(n)]
 
+
+def test_batch_tile_renderer_over_rccl_world1(V, O):
+    """The N > 1 driver (vokselis_amd.dist.BatchTileRenderer) as a world of one over the library's own RCCL
+    communicator (vk_comm_init_rank / vk_gather_tiles): batches of 4 frames, a new camera every frame, a partial
+    batch at the end; every delivered frame bitwise equal to vk_render's frame for that camera."""
     import torch
     import torch.distributed as dist
 
-    from vokselis_amd.dist import TileParallelRenderer
+    from vokselis_amd.dist import BatchTileRenderer
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    W, H = 320, 200
-    vol = O.volume_standin_u8(64)
-    cam_a = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-    ctx = V.Context(W, H, cam_a, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    ref_ctx = V.Context(W, H, cam_a, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    W, H = 640, 360
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
     try:
-        for c in (ctx, ref_ctx):
-            V.VolumeTexture(c, vol); c.update()
+        V.VolumeTexture.generate_standin(ctx, (128,) * 3)
+        cams = _orbit_cameras(V, 11, W / H)
+        pipe = V.RaycastPipeline(dt_scale=0.5)
+        want = []
+        for c in cams:
+            ctx.set_camera_blob(c)
+            pipe.record(ctx)
+            want.append(ctx.read_backbuffer().view(np.uint16).copy())
+        got = {}
 
-        def direct(dt):
-            V.RaycastPipeline(dt_scale=dt).record(ref_ctx)
-            return ref_ctx.read_backbuffer().view(np.uint16).copy()
-
-        for fif in (1, 2):  # frames in flight per rank: serial, and two streams
-          with torch.cuda.stream(torch.cuda.Stream()):  # the collective is ordered against torch's current stream
-            for c in (ctx, ref_ctx):
-                c.camera.set_zoom(1.0); c.update()
-            expect, bad = [], []
-
-            def check(k):
-                if not (ctx.read_backbuffer().view(np.uint16) == expect[k]).all():
-                    bad.append(k)
-
-            pipe = V.RaycastPipeline(dt_scale=1.0)
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=3, frames_in_flight=fif, on_frame=check)
-            for k, dt in enumerate((1.0, 0.5, 0.25, 0.75)):   # one full batch + one frame
-                pipe.dt_scale = dt
-                expect.append(direct(dt))
-                tpr.submit(k)
-            tpr.flush()
-            assert (ctx.read_backbuffer().view(np.uint16) == direct(0.75)).all()
-            pipe.dt_scale = 0.5
-            expect += [direct(0.5), direct(0.5)]
-            tpr.submit(4); tpr.submit(5)                      # partial batch under the old camera
-            # camera change inside a batch: the tiles are re-dealt (other order, other active set); the two frames
-            # above must still be delivered as they were marched
-            for c in (ctx, ref_ctx):
-                c.camera.set_zoom(2.5)
-                c.update()
-            expect.append(direct(0.5))
-            tpr.submit(6)
-            tpr.flush()
-            assert (ctx.read_backbuffer().view(np.uint16) == direct(0.5)).all()
-            assert tpr._delivered == 7 and not bad, (fif, bad)
-    finally:
-        ctx.close(); ref_ctx.close()
-        if created:
-            dist.destroy_process_group()
-
-
-def test_tile_parallel_renderer_orbiting_camera(V, O):
-    """A camera that changes every frame: each frame is dealt under its own tile order and delivered (later, while
-    newer frames are already marching) under that order's epoch -- no pipeline drain.  More camera changes than the
-    library keeps order tables for (16) pass through while at most two batches are pending."""
-    import os
-
-    import torch
-    import torch.distributed as dist
-
-    from vokselis_amd.dist import TileParallelRenderer
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    W, H = 320, 200
-    vol = O.volume_standin_u8(64)
-    ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    ref_ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    try:
-        for c in (ctx, ref_ctx):
-            V.VolumeTexture(c, vol); c.update()
-        expect, bad = [], []
-
-        def check(k):
-            if not (ctx.read_backbuffer().view(np.uint16) == expect[k]).all():
-                bad.append(k)
+        def on_batch(first, count, frames):
+            f = frames.cpu().numpy().view(np.uint16)
+            for j in range(count):
+                got[first + j] = f[j].copy()
 
         with torch.cuda.stream(torch.cuda.Stream()):
-            pipe = V.RaycastPipeline(dt_scale=0.5)
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=4, frames_in_flight=4, on_frame=check)
-            for k in range(40):
-                for c in (ctx, ref_ctx):
-                    c.camera.set_yaw(1.0 + 0.15 * k); c.camera.set_zoom(1.0 + 0.03 * k); c.update()
-                pipe.record(ref_ctx)
-                expect.append(ref_ctx.read_backbuffer().view(np.uint16).copy())
-                tpr.submit(k)
-            tpr.flush()
-        assert tpr._delivered == 40 and not bad, bad
+            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="rccl", on_batch=on_batch)
+            for c in cams:
+                r.submit(c)
+            r.close()
+            ctx.set_stream(None)
+        assert sorted(got) == list(range(11))
+        for k in range(11):
+            assert (got[k] == want[k]).all(), k
     finally:
-        ctx.close(); ref_ctx.close()
+        ctx.close()
         if created:
             dist.destroy_process_group()
 
 
-def _tpr_two_ranks_worker(rank, world, port, q):
-    """One of two processes sharing cuda:0: the production TileParallelRenderer with rank/world = (rank, 2); only the
-    wire is replaced (gloo through host memory -- RCCL refuses two ranks on one device)."""
+def _btr_two_ranks_worker(rank, world, port, q):
+    """One of two processes sharing cuda:0: the production BatchTileRenderer with rank/world = (rank, 2); only the
+    wire differs (gloo through host memory -- RCCL refuses two ranks on one device)."""
     import os
 
     import numpy as np
@@ -377,68 +318,47 @@ def _tpr_two_ranks_worker(rank, world, port, q):
     import torch.distributed as dist
 
     import vokselis_amd as V
-    from vokselis_amd.dist import FrameGather, TileParallelRenderer
+    from vokselis_amd.dist import BatchTileRenderer
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    class HostStagedGather(FrameGather):
-        def start(self, set_, n=None, count=None):
-            n = self.slots if n is None else min(int(n), self.slots)
-            count = self.batch if count is None else count
-            compact, gathered = self.buffers(n)
-            torch.cuda.current_stream().synchronize()          # the frames of this batch are marched
-            send = compact[set_][:count].cpu()
-            recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.root else None
-            self.dist.gather(send, gather_list=recv, dst=self.root, group=self.group)
-            if self.rank == self.root:
-                for r in range(self.world):
-                    gathered[set_][r, :count].copy_(recv[r])
-
-            class Done:
-                def wait(self_inner):
-                    return True
-            return Done()
-
     try:
         W, H = 640, 360
-        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-        ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-        V.VolumeTexture.generate_standin(ctx, (128,) * 3); ctx.update()
-        dts = (0.5, 1.0, 0.7)
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+        V.VolumeTexture.generate_standin(ctx, (128,) * 3)
+        cams = [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(11)]
+        pipe = V.RaycastPipeline(dt_scale=0.5)
         want = []
         if rank == 0:
-            ref = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-            V.VolumeTexture.generate_standin(ref, (128,) * 3); ref.update()
-            for dt in dts:
-                V.RaycastPipeline(dt_scale=dt).record(ref)
-                want.append(ref.read_backbuffer().view(np.uint16).copy())
-            ref.close()
-        bad = []
+            for c in cams:
+                ctx.set_camera_blob(c)
+                pipe.record(ctx)
+                want.append(ctx.read_backbuffer().view(np.uint16).copy())
+        bad, seen = [], []
 
-        def check(k):
-            got = ctx.read_backbuffer().view(np.uint16)
-            if not (got == want[k % 3]).all():
-                bad.append(k)
+        def on_batch(first, count, frames):
+            f = frames.cpu().numpy().view(np.uint16)
+            for j in range(count):
+                seen.append(first + j)
+                if not (f[j] == want[first + j]).all():
+                    bad.append(first + j)
 
         with torch.cuda.stream(torch.cuda.Stream()):
-            pipe = V.RaycastPipeline(dt_scale=dts[0])
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=4, frames_in_flight=4, gather_cls=HostStagedGather,
-                                       on_frame=check if rank == 0 else None)
-            for k in range(11):  # two full batches + a partial one
-                pipe.dt_scale = dts[k % 3]
-                tpr.submit(k)
-            tpr.flush()
+            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="torch", via_host=True, on_batch=on_batch if rank == 0 else None)
+            for c in cams:
+                r.submit(c)
+            r.close()
+            ctx.set_stream(None)
         ctx.close()
-        q.put((rank, tpr._delivered, bad))
+        q.put((rank, seen, bad))
     finally:
         dist.destroy_process_group()
 
 
-def test_tile_parallel_renderer_two_ranks_one_gpu(V, O):
-    """The N > 1 driver with two real ranks (two processes on this GPU): tiles dealt to both, batches of 4 frames, 4
-    frames in flight, every frame delivered on the root checked against the single-launch frame."""
+def test_batch_tile_renderer_two_ranks_one_gpu(V, O):
+    """The N > 1 driver with two real ranks (two processes on this GPU): every frame's tiles dealt to both, batches of
+    4 frames with a different camera each, a partial batch; every frame delivered on the root bitwise equal to vk_render's."""
     import socket
 
     import torch.multiprocessing as mp
@@ -448,63 +368,63 @@ def test_tile_parallel_renderer_two_ranks_one_gpu(V, O):
         port = s_.getsockname()[1]
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_tpr_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_btr_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
     for p_ in procs:
         p_.join(300)
         assert p_.exitcode == 0
     got = sorted(q.get(timeout=10) for _ in range(2))
-    assert got[0][0] == 0 and got[0][1] == 11 and got[0][2] == [], got
-    assert got[1][0] == 1 and got[1][1] == 11, got
+    assert got[0][0] == 0 and got[0][1] == list(range(11)) and got[0][2] == [], got
+    assert got[1][0] == 1, got
 
 
-def test_tile_parallel_renderer_frames_in_flight_stress(V, O):
-    """The bench configuration of the N > 1 driver (8 frames per gather, 8 frames in flight) on the C2 frame, as a
-    world of one: every delivered frame is checked, in order, against the single-launch frame of its own dt."""
+def test_group_api_and_plain_c_consumer(V, O, tmp_path):
+    """vk_group_* (one process, one context per GPU, ncclCommInitAll) on the GPUs this box has, and a plain-C program
+    (tests/cabi_smoke.c, gcc, no C++ / HIP headers) linked against the library: both must reproduce vk_render."""
+    import ctypes as C
     import os
+    import subprocess
 
     import torch
-    import torch.distributed as dist
 
-    from vokselis_amd.dist import TileParallelRenderer
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    W, H = 1920, 1080
-    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-    ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    ref_ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    L = V.native.lib()
+    W, H = 320, 200
+    n_gpus = torch.cuda.device_count()
+    ords = (C.c_int * n_gpus)(*range(n_gpus))
+    g = C.c_void_p()
+    assert L.vk_group_create(n_gpus, ords, C.byref(g)) == 0
     try:
-        dts = (0.5, 0.8, 1.3)
-        want = []
-        for c in (ctx, ref_ctx):
-            V.VolumeTexture.generate_standin(c, (256,) * 3); c.update()
-        for dt in dts:
-            V.RaycastPipeline(dt_scale=dt).record(ref_ctx)
-            want.append(ref_ctx.read_backbuffer().view(np.uint16).copy())
-        bad = []
-
-        def check(k):
-            got = ctx.read_backbuffer().view(np.uint16)  # synchronises the main stream: frame k is complete
-            if not (got == want[k % 3]).all():
-                bad.append(k)
-
-        with torch.cuda.stream(torch.cuda.Stream()):
-            pipe = V.RaycastPipeline(dt_scale=dts[0])
-            tpr = TileParallelRenderer(ctx, pipe, tile_size=64, batch=8, frames_in_flight=8, on_frame=check)
-            for k in range(29):  # three full batches + a partial one
-                pipe.dt_scale = dts[k % 3]
-                tpr.submit(k)
-            tpr.flush()
-        assert tpr._delivered == 29 and not bad, bad
+        assert L.vk_group_size(g) == n_gpus
+        vol = O.volume_standin_u8(48)
+        for i in range(n_gpus):
+            c = C.c_void_p(L.vk_group_ctx(g, i))
+            V.native.check(c, L.vk_backbuffer_resize(c, W, H, V.OUT_RGBA32F))
+            V.native.check(c, L.vk_volume_upload(c, vol.ctypes.data, None, 48, 48, 48, V.FMT_R8_UNORM, V.LAYOUT_AUTO))
+        cams = _orbit_cameras(V, 5, W / H)
+        root = C.c_void_p(L.vk_group_ctx(g, 0))
+        out = C.c_void_p()
+        V.native.check(root, L.vk_device_alloc(root, 5 * W * H * 16, C.byref(out)))
+        rc = L.vk_group_render(g, V.MODE_NAIVE_TRILINEAR, 5, b"".join(cams), 32, 0.5, 0, out)
+        assert rc == 0, L.vk_group_last_error(g)
+        assert L.vk_group_sync(g) == 0
+        got = np.empty((5, H, W, 4), np.float32)
+        V.native.check(root, L.vk_device_download(root, got.ctypes.data, out, got.nbytes))
+        V.native.check(root, L.vk_device_free(root, out))
     finally:
-        ctx.close(); ref_ctx.close()
-        if created:
-            dist.destroy_process_group()
+        L.vk_group_destroy(g)
+    for k, cam in enumerate(cams):
+        img, _, _ = gpu_render(V, cam, vol, W, H, dt=0.5, want_steps=False)
+        assert (img.view(np.uint32) == got[k].view(np.uint32)).all(), k
+    # the plain-C consumer
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_smoke")
+    lib_dir = os.path.join(root_dir, "vokselis_amd", "_lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root_dir, "include"), os.path.join(root_dir, "tests", "cabi_smoke.c"),
+                    "-L", lib_dir, "-lvokselis_hip", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cabi_smoke: OK" in r.stdout, r.stdout
 
 
 def test_f16_volume(V, O, golden, cameras):
@@ -952,3 +872,48 @@ def test_large_volume_layouts_agree(V, O):
     ys, xs = slice(tile[1], tile[1] + 64), slice(tile[0], tile[0] + 64)
     assert (steps["b9"][ys, xs] == rsteps[ys, xs]).all() and rsteps[ys, xs].min() > 0
     assert np.abs(imgs["b9"][ys, xs] - ref[ys, xs]).max() <= TOL
+
+
+@pytest.mark.parametrize("name,n,f16,W,H,seed,tile", [
+    ("C4", 1024, True, 1920, 1080, 0x5EED0004, (1216, 416, 64, 64)),
+    ("C5", 2048, False, 3840, 2160, 0x5EED0005, (2496, 864, 64, 64)),
+])
+def test_baseline_configs_full_size(V, O, name, n, f16, W, H, seed, tile):
+    """BASELINE configs C4 (1024^3 fp16 @1920x1080) and C5 (2048^3 uint8 @3840x2160) at their own size on one GPU:
+    AUTO picks the staged 8^3 bricks; the frame and the per-pixel trip counts are bitwise equal through three
+    independent layouts/kernels (staged bricks through LDS, dense 9^3 bricks, dense linear -- 64-bit offsets
+    everywhere); a 64x64 tile of it matches the CPU oracle on the host-generated volume."""
+    import ctypes as C
+
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
+    fmt = V.FMT_R16_FLOAT if f16 else V.FMT_R8_UNORM
+    imgs, steps = {}, {}
+    for lname, lay in (("auto", V.LAYOUT_AUTO), ("b9", V.LAYOUT_BRICKED), ("lin", V.LAYOUT_LINEAR)):
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture.generate_fog(ctx, (n, n, n), fmt=fmt, seed=seed, layout=lay)
+            if lname == "auto":
+                got_layout = C.c_int()
+                V.native.check(ctx.handle, V.native.lib().vk_volume_info(ctx.handle, None, None, C.byref(got_layout), None))
+                assert got_layout.value == V.LAYOUT_STAGED
+            ctx.set_camera_blob(cam)
+            ctx.reset_step_counts()
+            V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)
+            imgs[lname], steps[lname] = ctx.read_backbuffer(), ctx.read_steps()
+            s_ref, s_samp = ctx.step_counts()
+            assert s_ref == s_samp == int(steps[lname].astype(np.int64).sum())  # fog: every iteration fetches its taps
+            if lname == "auto":  # the production (uninstrumented) kernel gives the same frame
+                V.RaycastPipeline(dt_scale=0.5).record(ctx)
+                assert (ctx.read_backbuffer().view(np.uint32) == imgs["auto"].view(np.uint32)).all()
+        finally:
+            ctx.close()
+    for other in ("b9", "lin"):
+        assert (imgs["auto"].view(np.uint32) == imgs[other].view(np.uint32)).all(), (name, other)
+        assert (steps["auto"] == steps[other]).all(), (name, other)
+    assert steps["auto"].max() == 2 * n + 1  # dt_scale 0.5: <= 2n+1 iterations (SURVEY F7)
+    host = O.volume_fog_f16(n, seed=seed) if f16 else O.volume_fog_u8(n, seed=seed)
+    ref, rsteps, _ = O.render(cam, host, W, H, dt_scale=0.5, tile=tile)
+    ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
+    assert (steps["auto"][ys, xs] == rsteps[ys, xs]).all()
+    assert rsteps[ys, xs].min() > 100  # the tile lies inside the cube's silhouette
+    assert np.abs(imgs["auto"][ys, xs] - ref[ys, xs]).max() <= TOL

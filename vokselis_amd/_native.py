@@ -51,6 +51,18 @@ SYMBOLS = {
     "vk_partition_epoch": (C.c_int, [_vp, C.POINTER(_u32)]),
     "vk_render_batch": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _vp, C.c_int, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_untile_batch": (C.c_int, [_vp, _u32, _vp, _u32, _vp]),
+    "vk_comm_unique_id": (C.c_int, [_vp]),
+    "vk_comm_init_rank": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "vk_comm_destroy": (C.c_int, [_vp]),
+    "vk_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vk_gather_tiles": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
+    "vk_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "vk_group_destroy": (C.c_int, [_vp]),
+    "vk_group_size": (C.c_int, [_vp]),
+    "vk_group_ctx": (_vp, [_vp, C.c_int]),
+    "vk_group_render": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _f32, _u32, _vp]),
+    "vk_group_sync": (C.c_int, [_vp]),
+    "vk_group_last_error": (C.c_char_p, [_vp]),
     "vk_device_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "vk_device_free": (C.c_int, [_vp, _vp]),
     "vk_device_download": (C.c_int, [_vp, _vp, _vp, _sz]),

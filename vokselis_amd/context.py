@@ -113,6 +113,7 @@ class Context:
         # Context::new: Camera::new(1., 0.5, 1., (0.,0.,0.), w/h) when none is given (src/context.rs:124-132)
         self.camera = camera if camera is not None else Camera(1.0, 0.5, 1.0, (0.0, 0.0, 0.0), width / height)
         self.camera_epoch = 0  # bumped whenever a camera blob is uploaded (per-camera caches key on it)
+        self.camera_blob = None  # the 144 bytes last uploaded
         self.global_uniform = Uniform()
         bw, bh = backbuffer if backbuffer is not None else HdrBackBuffer.DEFAULT_RESOLUTION
         self.render_backbuffer = HdrBackBuffer(bw, bh, out_format)
@@ -156,7 +157,8 @@ class Context:
         gu.resolution = (float(self.width), float(self.height))
         N.check(self._h, N.lib().vk_set_uniform(self._h, gu.to_bytes()))
         if self.camera.updated or self._first_frame:
-            N.check(self._h, N.lib().vk_set_camera(self._h, self.camera.get_proj_view_matrix()))
+            self.camera_blob = self.camera.get_proj_view_matrix()
+            N.check(self._h, N.lib().vk_set_camera(self._h, self.camera_blob))
             self.camera.updated = False
             self._first_frame = False
             self.camera_epoch += 1
@@ -179,6 +181,7 @@ class Context:
 
     def set_camera_blob(self, blob: bytes):
         N.check(self._h, N.lib().vk_set_camera(self._h, blob))
+        self.camera_blob = bytes(blob)
         self._first_frame = False
         self.camera_epoch += 1
 
