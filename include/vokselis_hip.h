@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2
 
 typedef struct vk_ctx vk_ctx;
 
@@ -148,12 +148,6 @@ int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t ti
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots);
 int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                         float dt_scale, uint32_t flags, void *compact_out);
-/* The same launch placed on a caller-owned HIP stream without synchronising anything: several frames can be
- * in flight on different streams (each into its own compact buffer), which is what lets a rank holding 1/N of
- * a small frame keep its GPU busy.  The caller orders that stream against the consumer of `compact_out`.
- * VK_RENDER_COUNT is refused (the counters live on the context's own stream). */
-int vk_render_partition_on(vk_ctx *ctx, void *hip_stream, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
-                           float dt_scale, uint32_t flags, void *compact_out);
 /* The partition deals tiles heaviest-first (a launch/balance heuristic derived from the camera):
  * position q of the order belongs to rank q % nranks, slot q / nranks.  order_out[q] = row-major
  * tile id; identical on every rank for identical camera, volume dims and backbuffer size. */
@@ -167,15 +161,8 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
 /* Root side: scatter the gathered [nranks][slot_stride][ts][ts] pixels into the backbuffer; tiles beyond
  * the active ones are cleared to (0,0,0,1).  Uses the order of the LAST partition call on this context, so
  * frames marched before a camera change are un-tiled as they were dealt: deliver them before the next
- * partition call under the new camera (vokselis_amd/dist.py drains its pipeline at that point). */
+ * partition call under the new camera.  (A stream of frames with changing cameras: vk_render_batch.) */
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride);
-/* The order tables are versioned: vk_partition_epoch returns the epoch of the order the last partition / render call
- * used (it changes with the camera), and vk_untile_epoch scatters with the tables of that epoch -- the library keeps
- * the last 16 -- so a pipelined driver can keep marching under a new camera while older frames are still being
- * gathered, and deliver each frame under the order it was dealt with. */
-int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch);
-int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, uint32_t epoch);
-
 /* Several frames in ONE launch.  The reference keeps frames in flight through its queue (src/lib.rs:178-194 submits a
  * frame per RedrawRequested without waiting); here the grid itself spans n_frames frames, each with its own camera
  * (`cameras`: n_frames x 144-byte CameraUniform blobs, host memory) and its own heaviest-first tile order, dealt

@@ -21,7 +21,7 @@ def test_cabi_exports_every_declared_symbol(hip_built):
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert getattr(hip_built, name) is not None
-    assert hip_built.vk_abi_version() == 1
+    assert hip_built.vk_abi_version() == 2  # bumped in round 2: batch, comm, group entry points; per-stream partition calls removed
 
 
 def test_cabi_fails_loudly_without_gpu(hip_built):
@@ -148,3 +148,31 @@ def test_host_volume_generators_match_oracle(O):
         assert (volumes.fog_f16(dims, seed=9).view(np.uint16) == O.volume_fog_f16(dims, seed=9).view(np.uint16)).all()
     v = O.volume_standin_u8(128)
     assert 0.65 <= (v <= 25).mean() <= 0.9 and v.max() >= 232  # >= 65 % exactly transparent
+
+
+def test_camera_blob_is_byte_identical_across_hosts(O, tmp_path):
+    """One camera-blob builder: the same orbit gives the same 144 bytes from the Python host, the C++
+    host and the oracle -- 100 random orbits plus the two example cameras -- so rays and trip counts cannot depend on
+    which host drove the library."""
+    import subprocess
+
+    import __graft_entry__ as g
+    from vokselis_amd.camera import Camera
+
+    rng = np.random.default_rng(20261003)
+    orbits = [(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9), (3.0, -0.5, 1.0, (0.0, 0.0, 0.0), 1280 / 720)]
+    for _ in range(100):
+        orbits.append((float(np.float32(rng.uniform(0.3, 6.0))), float(np.float32(rng.uniform(-1.55, 1.55))), float(np.float32(rng.uniform(-7.0, 7.0))),
+                       tuple(float(np.float32(v)) for v in rng.uniform(-0.5, 1.0, 3)), float(np.float32(rng.choice([1.0, 16 / 9, 4 / 3, 0.6])))))
+    py = [Camera(z, p, y, t, a).get_proj_view_matrix() for z, p, y, t, a in orbits]
+    orc = [O.camera_blob(z, p, y, t, a) for z, p, y, t, a in orbits]
+    assert py == orc
+    g.build_host()
+    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "bonsai")
+    txt, out = tmp_path / "orbits.txt", tmp_path / "blobs.bin"
+    txt.write_text("".join("%r %r %r %r %r %r %r\n" % (z, p, y, t[0], t[1], t[2], a) for z, p, y, t, a in orbits))
+    r = subprocess.run([exe, "--camera-blobs", str(txt), str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    cpp = out.read_bytes()
+    assert len(cpp) == 144 * len(orbits)
+    assert [cpp[144 * i:144 * (i + 1)] for i in range(len(orbits))] == py

@@ -43,12 +43,9 @@ SYMBOLS = {
     "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
     "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
     "vk_render_partition": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),
-    "vk_render_partition_on": (C.c_int, [_vp, _vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),
     "vk_partition_order": (C.c_int, [_vp, C.c_int, _u32, C.POINTER(_u32), _u32]),
     "vk_partition_active": (C.c_int, [_vp, C.c_int, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_untile": (C.c_int, [_vp, _vp, _u32, _u32, _u32]),
-    "vk_untile_epoch": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32]),
-    "vk_partition_epoch": (C.c_int, [_vp, C.POINTER(_u32)]),
     "vk_render_batch": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _vp, C.c_int, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_untile_batch": (C.c_int, [_vp, _u32, _vp, _u32, _vp]),
     "vk_comm_unique_id": (C.c_int, [_vp]),

@@ -7,11 +7,30 @@ matrices column-major).
 """
 from __future__ import annotations
 
+import ctypes
+import ctypes.util
 import math
 
 import numpy as np
 
 f32 = np.float32
+
+# One camera-blob builder: every host builds the 144 bytes with the same binary32 operations in the
+# same order, so the same orbit gives the same bytes -- and therefore the same rays and trip counts -- from Python,
+# from the C++ host and from the test oracle.  Sines and cosines are the C library's binary32 sinf / cosf (numpy's own
+# float32 sine may differ from it in the last place), the inverse is the f32 cofactor expansion written out below.
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+for _fn in (_libm.sinf, _libm.cosf):
+    _fn.restype = ctypes.c_float
+    _fn.argtypes = [ctypes.c_float]
+
+
+def sinf(x) -> np.float32:
+    return f32(_libm.sinf(float(f32(x))))
+
+
+def cosf(x) -> np.float32:
+    return f32(_libm.cosf(float(f32(x))))
 
 
 def _v3(x) -> np.ndarray:
@@ -47,7 +66,7 @@ def look_at_rh(eye, center, up) -> np.ndarray:
 def perspective_rh(fovy, aspect, z_near, z_far) -> np.ndarray:
     """glam 0.20.5 Mat4::perspective_rh (depth 0..1); [column][row]."""
     half = f32(0.5) * f32(fovy)
-    sn, cs = f32(math.sin(half)), f32(math.cos(half))
+    sn, cs = sinf(half), cosf(half)
     h = f32(cs / sn)
     w = f32(h / f32(aspect))
     r = f32(f32(z_far) / f32(f32(z_near) - f32(z_far)))
@@ -67,10 +86,31 @@ def mat4_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 
 def mat4_inverse(m: np.ndarray) -> np.ndarray:
-    """General 4x4 inverse.  glam's SIMD cofactor ordering cannot be reproduced bit for bit
-    offline; the hot path only consumes the resulting blob."""
-    inv = np.linalg.inv(m.astype(np.float64).T).T  # [column][row] <-> math convention
-    return inv.astype(np.float32)
+    """General 4x4 inverse by cofactors, binary32 throughout, products and sums left to right as written (glam's
+    SIMD ordering cannot be reproduced offline; this order is the one every host of this build
+    uses).  m and the result are [column][row]."""
+    m = [f32(v) for v in np.asarray(m, np.float32).reshape(16)]
+    a = [f32(0)] * 16
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10]
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10]
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9]
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9]
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10]
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10]
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9]
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9]
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6]
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6]
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5]
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5]
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6]
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6]
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5]
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5]
+    det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rdet = f32(1.0) / det
+        return np.array([v * rdet for v in a], dtype=np.float32).reshape(4, 4)
 
 
 class Camera:
@@ -130,11 +170,8 @@ class Camera:
 
     def _fix_eye(self):
         # src/camera.rs:148-157
-        pitch_cos = f32(math.cos(self.pitch))
-        v = np.array(
-            [f32(math.sin(self.yaw)) * pitch_cos, f32(math.sin(self.pitch)), f32(math.cos(self.yaw)) * pitch_cos],
-            dtype=np.float32,
-        )
+        pitch_cos = cosf(self.pitch)
+        v = np.array([sinf(self.yaw) * pitch_cos, sinf(self.pitch), cosf(self.yaw) * pitch_cos], dtype=np.float32)
         self.eye = (self.target - self.zoom * v).astype(np.float32)
 
     def set_aspect(self, width: int, height: int):

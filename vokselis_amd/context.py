@@ -337,15 +337,10 @@ class RaycastPipeline:
         tx, ty, tw, th = (0, 0, bb.width, bb.height) if tile is None else tile
         N.check(ctx.handle, N.lib().vk_render(ctx.handle, self.mode, tx, ty, tw, th, self.dt_scale, self.flags))
 
-    def record_partition(self, ctx: Context, tile_size: int, rank: int, nranks: int, compact_ptr: int, stream: int | None = None):
-        """March this rank's tiles into a compact buffer; `stream` places the launch on a caller-owned HIP
-        stream without synchronising (frames in flight), default: the context's stream."""
-        if stream:
-            N.check(ctx.handle, N.lib().vk_render_partition_on(ctx.handle, C.c_void_p(stream), self.mode, tile_size, rank, nranks,
-                                                              self.dt_scale, self.flags, C.c_void_p(compact_ptr)))
-        else:
-            N.check(ctx.handle, N.lib().vk_render_partition(ctx.handle, self.mode, tile_size, rank, nranks, self.dt_scale,
-                                                           self.flags, C.c_void_p(compact_ptr)))
+    def record_partition(self, ctx: Context, tile_size: int, rank: int, nranks: int, compact_ptr: int):
+        """March this rank's tiles of the current camera's frame into a compact buffer (several frames: render_batch)."""
+        N.check(ctx.handle, N.lib().vk_render_partition(ctx.handle, self.mode, tile_size, rank, nranks, self.dt_scale,
+                                                       self.flags, C.c_void_p(compact_ptr)))
 
 
 def render_batch(ctx: Context, pipe: RaycastPipeline, cameras, out_ptr: int, *, tile_size: int = 64, rank: int = 0, nranks: int = 1,

@@ -896,9 +896,11 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     }
     const size_t cap = ctx->d_order_cap;
     const int slot = (int)((ctx->order_epoch + 1u) % (uint32_t)kOrderRing);  // epoch e lives in slot e % kOrderRing
-    // the slot's previous upload (kOrderRing cameras ago) has long completed; waiting on it also makes the pinned
-    // staging safe to rewrite.  Launches that still READ that old slot would have to be > kOrderRing - 1 cameras
-    // behind: the N > 1 driver drains at every camera change, single-stream use is stream-ordered.
+    // Waiting on the slot's previous upload (kOrderRing cameras ago) makes the pinned staging safe to rewrite.  The
+    // device slot itself is safe to overwrite because a context works on ONE stream: the kernels that read the slot
+    // kOrderRing cameras ago were enqueued on ctx->stream before this copy (vk_ctx_set_stream drains the old stream
+    // first), so the copy is stream-ordered after them.  (Frames in flight are batched launches now, vk_render_batch,
+    // which carry their own tables.)
     if (ctx->ring_ev[slot]) HIP_TRY(ctx, hipEventSynchronize(ctx->ring_ev[slot]));
     else HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ring_ev[slot], hipEventDisableTiming));
     uint32_t *hs = ctx->h_ring + (size_t)slot * 2 * cap, *ds = ctx->d_ring + (size_t)slot * 2 * cap;
@@ -1121,26 +1123,15 @@ int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank
     return render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
 }
 
-int vk_render_partition_on(vk_ctx *ctx, void *hip_stream, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
-                           float dt_scale, uint32_t flags, void *compact_out) {
-    if (!ctx) return VK_ERR_INVALID;
-    if (!compact_out || !hip_stream) return fail(ctx, VK_ERR_INVALID, "vk_render_partition_on: NULL argument");
-    if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_partition_on: counters belong to the context's own stream");
-    // Frames in flight: the launch goes to the caller's stream, nothing is synchronised.  The caller orders
-    // that stream against whatever consumes / recycles `compact_out`.
-    hipStream_t saved = ctx->stream;
-    ctx->stream = (hipStream_t)hip_stream;
-    const int rc = render_common(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, rank, nranks, dt_scale, flags, compact_out);
-    ctx->stream = saved;
-    return rc;
-}
-
 int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nranks, uint32_t *n_active_tiles, uint32_t *n_active_slots) {
     if (!ctx) return VK_ERR_INVALID;
-    if (!ctx->backbuffer || !ctx->have_camera || ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "vk_partition_active: needs volume, camera and backbuffer");
+    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "unknown mode");
+    if (!ctx->backbuffer || !ctx->have_camera || (ctx->format < 0 && mode != VK_MODE_PROCEDURAL))
+        return fail(ctx, VK_ERR_INVALID, "vk_partition_active: needs camera and backbuffer (and a volume, except PROCEDURAL)");
     if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int orc = tile_order_update(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+    // the same geometry key as the render calls use (PROCEDURAL marches the compute twin's rays)
+    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
     if (orc) return orc;
     if (n_active_tiles) *n_active_tiles = ctx->order_active;
     if (n_active_slots) *n_active_slots = (ctx->order_active + nranks - 1) / nranks;
@@ -1162,45 +1153,37 @@ int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n) {
 
 int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *order_out, uint32_t n_tiles) {
     if (!ctx || !order_out) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: NULL argument");
-    if (!ctx->backbuffer || !ctx->have_camera || ctx->format < 0) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: needs volume, camera and backbuffer");
+    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST && mode != VK_MODE_PROCEDURAL) return fail(ctx, VK_ERR_INVALID, "unknown mode");
+    if (!ctx->backbuffer || !ctx->have_camera || (ctx->format < 0 && mode != VK_MODE_PROCEDURAL))
+        return fail(ctx, VK_ERR_INVALID, "vk_partition_order: needs camera and backbuffer (and a volume, except PROCEDURAL)");
     if (tile_size == 0 || (tile_size & 7u)) return fail(ctx, VK_ERR_INVALID, "tile size must be a multiple of 8");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int orc = tile_order_update(ctx, mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
     if (orc) return orc;
     if (n_tiles != ctx->order.size()) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: n_tiles does not match the partition");
     std::memcpy(order_out, ctx->order.data(), n_tiles * sizeof(uint32_t));
     return VK_OK;
 }
 
-static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, bool by_epoch, uint32_t epoch) {
+static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride) {
     if (!ctx || !gathered) return fail(ctx, VK_ERR_INVALID, "vk_untile: NULL argument");
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
     if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "vk_untile: bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_camera) return fail(ctx, VK_ERR_INVALID, "vk_untile: no camera (the tile order follows the camera)");
     const uint32_t tiles_x = (ctx->width + tile_size - 1) / tile_size;
-    const uint32_t *d_pos = nullptr;
-    uint32_t n_active = 0;
-    if (by_epoch) {
-        const int s = (int)(epoch % 16u);
-        if (epoch == 0 || ctx->order_epoch - epoch >= 16u || ctx->ring_epoch[s] != epoch || !ctx->d_ring)
-            return fail(ctx, VK_ERR_INVALID, "vk_untile_epoch: that order is no longer held (more than 15 order changes ago)");
-        d_pos = ctx->d_ring + (size_t)s * 2 * ctx->d_order_cap + ctx->d_order_cap;
-        n_active = ctx->ring_active[s];
-        if (!ctx->ring_done[s] && ctx->stream != ctx->ring_stream[s]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_ev[s], 0));
-    } else {
-        // The un-tile follows the order the partitions were marched with: the tables of the LAST partition call,
-        // not those of a camera uploaded since.  Only a context that has never partitioned this frame shape derives them here.
-        const size_t n_tiles = (size_t)tiles_x * ((ctx->height + tile_size - 1) / tile_size);
-        if (!ctx->d_order_pos || ctx->order.size() != n_tiles) {
-            int orc = tile_order_update(ctx, ctx->format == VK_FMT_RGBA16F_PAIR ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
-            if (orc) return orc;
-        }
-        int owc = order_wait(ctx);
-        if (owc) return owc;
-        d_pos = ctx->d_order_pos;
-        n_active = ctx->order_active;
+    // The un-tile follows the order the partitions were marched with: the tables of the LAST partition call,
+    // not those of a camera uploaded since.  Only a context that has never partitioned this frame shape derives them here.
+    const size_t n_tiles = (size_t)tiles_x * ((ctx->height + tile_size - 1) / tile_size);
+    if (!ctx->d_order_pos || ctx->order.size() != n_tiles) {
+        const int m = ctx->format == VK_FMT_RGBA16F_PAIR || ctx->format < 0 ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR;
+        int orc = tile_order_update(ctx, m, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
+        if (orc) return orc;
     }
+    int owc = order_wait(ctx);
+    if (owc) return owc;
+    const uint32_t *d_pos = ctx->d_order_pos;
+    const uint32_t n_active = ctx->order_active;
     const uint64_t n = (uint64_t)ctx->width * ctx->height;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
@@ -1213,19 +1196,8 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
 }
 
 int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride) {
-    return untile_common(ctx, gathered, tile_size, nranks, slot_stride, false, 0);
+    return untile_common(ctx, gathered, tile_size, nranks, slot_stride);
 }
-
-int vk_untile_epoch(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nranks, uint32_t slot_stride, uint32_t epoch) {
-    return untile_common(ctx, gathered, tile_size, nranks, slot_stride, true, epoch);
-}
-
-int vk_partition_epoch(vk_ctx *ctx, uint32_t *epoch) {
-    if (!ctx || !epoch) return VK_ERR_INVALID;
-    *epoch = ctx->order_epoch;
-    return VK_OK;
-}
-
 
 // ---- batched launches -----------------------------------------------------------------------------
 
