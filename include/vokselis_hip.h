@@ -73,9 +73,11 @@ enum vk_render_flags {
     VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
     VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
     VK_RENDER_SAFE = 4,     /* force the clamped / 64-bit-offset kernel variant */
-    VK_RENDER_FORCE_SKIP = 8, /* skip even when < 10 % of the cells are transparent (default: auto) */
+    VK_RENDER_FORCE_SKIP = 8, /* use the skip kernel (with adaptive probing) whatever the census of transparent cells (default: from 30 %) */
     VK_RENDER_DEBUG_TRIPS = 16, /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
-    VK_RENDER_DEBUG_FALLBACK = 32 /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
+    VK_RENDER_DEBUG_FALLBACK = 32, /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
+    VK_RENDER_PROBE_ALWAYS = 64 /* skip kernels: look the distance map up on every trip (no adaptive dense stretches): S_sampled is then
+                                   exactly the number of steps that can contribute; the frame is the same either way */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */

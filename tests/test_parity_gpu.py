@@ -33,7 +33,9 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
         ctx.set_camera_blob(cam_blob)
         ctx.reset_step_counts()
         if not (flags & V.RENDER_NO_SKIP):
-            flags |= V.RENDER_FORCE_SKIP  # exercise the skip path whatever the volume's empty share
+            # exercise the skip path whatever the volume's empty share, probing on every trip so that S_sampled is exactly
+            # the count of steps that can contribute (the adaptive policy has its own test)
+            flags |= V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS
         pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR if mode is None else mode, dt_scale=dt,
                                  flags=flags | (V.RENDER_COUNT if want_steps else 0))
         pipe.record(ctx, tile)
@@ -100,6 +102,57 @@ def test_skip_is_exact(V, O):
     assert (a.view(np.uint32) == b.view(np.uint32)).all() and (a.view(np.uint32) == c.view(np.uint32)).all()
     assert (sa == sb).all() and (sa == sc).all() and ra == rb
     assert ma < mb == rb  # without skipping every iteration fetches taps
+
+
+def _holes_volume(n, p_empty, seed=3, block=16):
+    """u8 fog 26..40 (every cell contributes) with 16^3 blocks knocked out to value 10 (exactly transparent) with
+    probability p_empty: the share of skippable cells is close to p_empty."""
+    rng = np.random.default_rng(seed)
+    vol = rng.integers(26, 41, (n, n, n), dtype=np.uint8)
+    nb = n // block
+    holes = rng.random((nb, nb, nb)) < p_empty
+    mask = np.repeat(np.repeat(np.repeat(holes, block, 0), block, 1), block, 2)
+    vol[mask] = 10
+    return vol
+
+
+def test_adaptive_skip_policy_is_exact(V, O):
+    """The default skip policy probes in windows and runs dense stretches where nothing can be skipped (fog), so that
+    skipping never costs more than a few per cent.  Whatever it decides the frame is the same bit for bit: against
+    the no-skip kernel, the probe-always kernel and the oracle, on fog, on volumes with 20 % and 60 % of their
+    cells knocked out, and on the bonsai stand-in; its tap-fetching steps lie between the exact count and S_ref."""
+    W, H = 320, 200
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
+    vols = {"fog": O.volume_fog_u8(96), "holes20": _holes_volume(96, 0.2), "holes60": _holes_volume(96, 0.6), "standin": O.volume_standin_u8(96),
+            "f16core": None}
+    z, y, x = np.meshgrid(np.arange(64), np.arange(64), np.arange(64), indexing="ij")
+    r2 = (x - 30) ** 2 + (y - 28) ** 2 + (z - 34) ** 2
+    vols["f16core"] = np.where(r2 < 150, 0.95, np.where(r2 < 700, 0.3, 0.05)).astype(np.float16)
+    for name, vol in vols.items():
+        ref, rsteps, rsamp = O.render(cam, vol, W, H, dt_scale=0.5)
+        res = {}
+        for mode, fl in (("noskip", V.RENDER_NO_SKIP), ("always", V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS), ("adaptive", V.RENDER_FORCE_SKIP),
+                         ("adaptive_safe", V.RENDER_FORCE_SKIP | V.RENDER_SAFE)):
+            ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+            try:
+                V.VolumeTexture(ctx, vol, layout=V.LAYOUT_PACKED if vol.dtype == np.float16 else V.LAYOUT_PACKED_PAIRS)
+                ctx.set_camera_blob(cam)
+                ctx.reset_step_counts()
+                V.RaycastPipeline(dt_scale=0.5, flags=fl | V.RENDER_COUNT).record(ctx)
+                img, steps, (s_ref, s_samp) = ctx.read_backbuffer(), ctx.read_steps(), ctx.step_counts()
+                V.RaycastPipeline(dt_scale=0.5, flags=fl).record(ctx)  # the production kernel
+                assert (ctx.read_backbuffer().view(np.uint32) == img.view(np.uint32)).all(), (name, mode)
+                res[mode] = (img, steps, s_ref, s_samp)
+            finally:
+                ctx.close()
+        for mode in ("always", "adaptive", "adaptive_safe"):
+            assert (res[mode][0].view(np.uint32) == res["noskip"][0].view(np.uint32)).all(), (name, mode)
+            assert (res[mode][1] == rsteps).all() and res[mode][2] == int(rsteps.sum()), (name, mode)
+        assert np.abs(res["adaptive"][0] - ref).max() <= TOL
+        assert res["always"][3] == int(rsamp.sum())
+        assert res["always"][3] <= res["adaptive"][3] <= res["noskip"][3] == res["noskip"][2], name
+        if name in ("holes60", "standin"):
+            assert res["adaptive"][3] < 0.8 * res["noskip"][3], name  # it still skips where there is something to skip
 
 
 def test_fog_never_terminates_early(V, O):

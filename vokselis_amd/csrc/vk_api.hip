@@ -515,8 +515,8 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         nb.empty_fraction = (double)ne / (double)n_cells;
     }
     // Distance maps.  Eight one-sided maps (one per ray octant) when skipping will be on by default
-    // (>= 10 % empty cells) and they stay <= 2 GiB; otherwise one isotropic map serves every octant.
-    const bool octants = nb.empty_fraction >= 0.10 && n_cells <= (1ull << 28);
+    // (>= 30 % empty cells) and they stay <= 2 GiB; otherwise one isotropic map serves every octant.
+    const bool octants = nb.empty_fraction >= 0.30 && n_cells <= (1ull << 28);  // the default policy skips from 30 % empty cells
     const uint64_t dist_bytes = octants ? 8 * n_cells : n_cells;
     if ((rc = alloc((void **)&nb.dist, dist_bytes, "distance map"))) return rc;
     nb.vol_bytes = n_cells * cell_bytes + dist_bytes;
@@ -960,7 +960,8 @@ static int check_render(vk_ctx *ctx, int mode, const float *cam, float dt_scale,
 
 // Launch the march kernel of the context's volume for a filled LaunchDesc (one frame or a batch).
 // `reach_cam`: the camera whose distance decides whether the unclamped fast path is safe (the farthest of a batch).
-static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L, uint32_t flags, const float *reach_cam) {
+static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags, const float *reach_cam) {
+    LaunchDesc L = L_in;
     const bool count = (flags & VK_RENDER_COUNT) != 0;
     VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
@@ -1001,9 +1002,16 @@ static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L, uint32_t f
             else hipLaunchKernelGGL((raymarch_compute_kernel<OUT_RGBA32F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, V);
         }
     } else {
-        // Skipping costs a distance lookup per iteration; it only pays when there is something to skip.
-        // Default: on iff >= 10 % of the cells are exactly transparent (fog volumes: off).
-        const bool skip = !(flags & VK_RENDER_NO_SKIP) && ((flags & VK_RENDER_FORCE_SKIP) || ctx->empty_fraction >= 0.10);
+        // Skipping costs a distance lookup per probing trip; it only pays when there is something to skip
+        // (tools/skip_crossover.py, DESIGN.md section 4: on 256^3 volumes with a share e of exactly-transparent cells
+        // the skip kernel overtakes the dense one between e = 0.36 and e = 0.56).  Default policy by the census taken
+        // at upload:  e < 0.30: the dense kernel;  0.30 <= e < 0.70: the skip kernel with adaptive probing (dense
+        // stretches where nothing is being skipped);  e >= 0.70: the skip kernel probing on every trip (mostly
+        // empty volumes -- the bonsai stand-in is at 0.77 -- spend their time in the skip walks, and the stretches only cost).
+        // VK_RENDER_FORCE_SKIP takes the skip kernel whatever the census, adaptive unless VK_RENDER_PROBE_ALWAYS.
+        const bool forced = (flags & VK_RENDER_FORCE_SKIP) != 0;
+        const bool skip = !(flags & VK_RENDER_NO_SKIP) && (forced || ctx->empty_fraction >= 0.30);
+        if (skip && !forced && ctx->empty_fraction >= 0.70) L.debug_flags &= ~4u;
         // SAFE=false (no per-axis clamps, 32-bit offsets, index tables in LDS) only when provably
         // harmless: the cell array is < 4 GiB, the tables fit a modest LDS budget, and the camera is
         // near enough that the accumulated position stays within 0.5/n of the box
@@ -1085,7 +1093,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.trace = nullptr;
     L.frames = nullptr;
     L.n_frames = 1;
-    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u);
+    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u);
     if (count && ctx->want_trace) {
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);
@@ -1280,7 +1288,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.compact = compact ? 1u : 0u;
     L.dt_scale = dt_scale;
     L.out = out;
-    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = 0;
+    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = (flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u;
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
     L.n_frames = n_frames;
     const int rc = dispatch_march(ctx, mode, L, flags, far_cam);

@@ -93,7 +93,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
-    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory
+    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory; bit 2: adaptive probing (skip kernels)
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
     // batched launch: the grid spans n_frames frames, position-major (slot 0 of every frame, then slot 1, ...), so
     // the heaviest tiles of all frames start first.  frames == nullptr: one frame, described by the fields above.
@@ -409,6 +409,7 @@ static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
 
 struct Census {  // SIMT execution census + step counters (COUNT builds only)
     uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0, n_fb = 0;
+    uint32_t skips = 0;  // trips that skipped (every build: drives the adaptive probing policy)
 };
 
 // Runs at most `budget` trips of the reference loop (raycast_naive.wgsl:101-119) on the state and
@@ -491,6 +492,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 if (SKIP) d = V.dist[idx + doff];
             }
             if (SKIP && d != 0) {
+                if (BOUNDED) cs.skips++;
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
                 // u + j*du; it is skipped iff its cell provably stays in that range on every axis:
                 // j*|du| < d - f (moving up) or j*|du| <= f + d - 1 (moving down), minus the margins:
@@ -614,27 +616,30 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
 // to them -- it is the lone heavy waves at the tail of a frame that set the frame time.  The f32
 // operations on t, p, A and the colour sums are those of march(), in the same order per variable.
 // The request one step past the ray's end reads a real (clamped) table entry and is never used.
-template <int VOL, bool COUNT>
-__device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, Census &cs, const uint32_t *lut) {
+// CELL_LUT: the tables hold cell indices (the skip kernels' copy) instead of byte offsets; `budget` bounds the trips
+// (0xffffffff: none) so that the skip kernels can run stretches of it between probing windows.
+template <int VOL, bool COUNT, bool CELL_LUT = false>
+__device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, Census &cs, const uint32_t *lut, uint32_t budget = 0xffffffffu) {
     float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
     const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, (uint32_t)V.max_off + (1u << V.sh_x));
-    if (!(t < t1 && A < 0.95f)) return;
+    if (!(t < t1 && A < 0.95f)) return false;
+    const uint32_t lsh = CELL_LUT ? V.sh_x : 0u;
     float fx, fy, fz;
     CellBits<VOL> c0, c1;  // two cell buffers, used alternately (no register copies between trips)
     {
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
-        c0 = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
+        c0 = load_cell<VOL>(cells, (lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]) << lsh);
     }
     // one trip: request `nxt` for the advanced position, evaluate `cur`; returns whether the ray goes on
     auto trip = [&](const CellBits<VOL> &cur, CellBits<VOL> &nxt) -> bool {
         if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; if (wave_leader()) { cs.w_outer++; cs.w_sample++; } }
         px = px + sx; py = py + sy; pz = pz + sz;  // :118
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
-        nxt = load_cell<VOL>(cells, lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]);
+        nxt = load_cell<VOL>(cells, (lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2]) << lsh);
         float c00, c10, c01, c11;
         xlerp_cell<VOL>(cur, fx, c00, c10, c01, c11);
         float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
@@ -654,14 +659,18 @@ __device__ __forceinline__ void march_stream(const VolumeDesc &V, RayState &r, C
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
         return t < t1 && A < 0.95f;
     };
+    bool alive = true;
     for (;;) {
-        if (!trip(c0, c1)) break;
-        if (!trip(c1, c0)) break;
+        if (!trip(c0, c1)) { alive = false; break; }
+        if (budget != 0xffffffffu && --budget == 0u) break;
+        if (!trip(c1, c0)) { alive = false; break; }
+        if (budget != 0xffffffffu && --budget == 0u) break;
     }
     // The last requests are consumed here, on the exit path too: with a use on both sides of the exit
     // branch the compiler cannot sink a request behind it (which would undo the pipelining).
     asm volatile("" ::"v"(c0.v), "v"(c1.v));
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    return alive;
 }
 
 // The dense 9^3-brick layouts, software-pipelined the same way: these serve volumes far larger than
@@ -875,6 +884,29 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
+        else if constexpr (SKIP) {
+            if (L.debug_flags & 4u) {
+                // Adaptive probing (wave-uniform policy, any policy is exact: a sampled empty cell adds +0).  Probe for a
+                // window of 16 trips; if fewer than 1 in 8 of the wave's live rays skipped anything in it, the wave is in
+                // material that cannot be skipped: run the dense loop -- no distance look-up, and on the fast path
+                // software-pipelined -- for a stretch that doubles every time the next window confirms it (32 .. 256
+                // trips), then probe again.  Fog pays ~6 % of its trips at the probing price instead of all of them.
+                uint32_t stretch = 32;
+                for (;;) {
+                    cs.skips = 0;
+                    bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr);
+                    const unsigned long long live = __ballot(alive);
+                    if (live == 0ull) break;
+                    if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = 32; continue; }
+                    if constexpr (USE_LUT) alive = march_stream<VOL, COUNT, true>(V, r, cs, cell_lut, stretch);
+                    else alive = march<VOL, false, SAFE, COUNT, true>(V, r, stretch, cs, nullptr);
+                    if (__ballot(alive) == 0ull) break;
+                    stretch = min(stretch * 2u, 256u);
+                }
+            } else {
+                march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
+            }
+        }
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);
         else if constexpr (VOL == VOL_Q8 || VOL == VOL_QF16) march_quads_stream<VOL, COUNT>(V, r, cs);
         else march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
