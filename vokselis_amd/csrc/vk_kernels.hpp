@@ -1401,6 +1401,15 @@ __global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, u
 // cs_main for every voxel: fbm value noise (3 octaves x 8 sin-hashes) and its finite-difference
 // gradient (3 more evaluations).  ALU-bound: 96 hashes per voxel.  hash()'s sine is the specified
 // one (f64 Cody-Waite + minimax polynomial, rounded once to f32), so the volume is reproducible.
+// a * b + k with the (wave-uniform, loop-invariant) coefficient k read from a scalar register pair.  Written out
+// because the compiler otherwise turns every Horner step into v_mov_b64 (copy the coefficient) + v_fmac_f64: 258 of
+// the procedural loop's 1068 instructions were such copies.  Same single-rounding fma, bit for bit.
+__device__ __forceinline__ double fma_k(double a, double b, double k) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
 __device__ __forceinline__ float sin_spec(float h) {
     const double x = (double)h;
     const double k = rint(x * 0.63661977236758134308);
@@ -1408,27 +1417,27 @@ __device__ __forceinline__ float sin_spec(float h) {
     r = fma(-k, 6.07710050650619224932e-11, r);
     const double r2 = r * r;
     double sp = 1.58969099521155010221e-10;
-    sp = fma(sp, r2, -2.50507602534068634195e-08);
-    sp = fma(sp, r2, 2.75573137070700676789e-06);
-    sp = fma(sp, r2, -1.98412698298579493134e-04);
-    sp = fma(sp, r2, 8.33333333332248946124e-03);
-    sp = fma(sp, r2, -1.66666666666666324348e-01);
+    sp = fma_k(sp, r2, -2.50507602534068634195e-08);
+    sp = fma_k(sp, r2, 2.75573137070700676789e-06);
+    sp = fma_k(sp, r2, -1.98412698298579493134e-04);
+    sp = fma_k(sp, r2, 8.33333333332248946124e-03);
+    sp = fma_k(sp, r2, -1.66666666666666324348e-01);
     const double sn = fma(r * r2, sp, r);
     double cp = -1.13596475577881948265e-11;
-    cp = fma(cp, r2, 2.08757232129817482790e-09);
-    cp = fma(cp, r2, -2.75573143513906633035e-07);
-    cp = fma(cp, r2, 2.48015872894767294178e-05);
-    cp = fma(cp, r2, -1.38888888888741095749e-03);
-    cp = fma(cp, r2, 4.16666666666666019037e-02);
+    cp = fma_k(cp, r2, 2.08757232129817482790e-09);
+    cp = fma_k(cp, r2, -2.75573143513906633035e-07);
+    cp = fma_k(cp, r2, 2.48015872894767294178e-05);
+    cp = fma_k(cp, r2, -1.38888888888741095749e-03);
+    cp = fma_k(cp, r2, 4.16666666666666019037e-02);
     const double cs = fma(r2 * r2, cp, fma(-0.5, r2, 1.0));
-    const long q = (long)k & 3;
+    const int q = (int)k & 3;  // |k| < 2^31 for every argument the hash makes
     const double v = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
     return (float)v;
 }
 __device__ __forceinline__ float xor_fract(float x) { return x - floorf(x); }
 __device__ __forceinline__ float xor_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 __device__ __forceinline__ float xor_hash(float h) { return xor_fract(sin_spec(h) * 43758.5453123f); }
-__device__ float xor_noise(float x0, float x1, float x2) {
+__device__ __forceinline__ float xor_noise(float x0, float x1, float x2) {
     const float p0 = floorf(x0), p1 = floorf(x1), p2 = floorf(x2);
     float f0 = xor_fract(x0), f1 = xor_fract(x1), f2 = xor_fract(x2);
     f0 = f0 * f0 * (3.0f - 2.0f * f0); f1 = f1 * f1 * (3.0f - 2.0f * f1); f2 = f2 * f2 * (3.0f - 2.0f * f2);
@@ -1437,7 +1446,7 @@ __device__ float xor_noise(float x0, float x1, float x2) {
                    xor_mix(xor_mix(xor_hash(n + 113.0f), xor_hash(n + 114.0f), f0), xor_mix(xor_hash(n + 270.0f), xor_hash(n + 271.0f), f0), f1),
                    f2);
 }
-__device__ float xor_fbm(float p0, float p1, float p2) {
+__device__ __forceinline__ float xor_fbm(float p0, float p1, float p2) {
     float f = 0.5000f * xor_noise(p0, p1, p2);
     p0 = p0 * 2.01f; p1 = p1 * 2.01f; p2 = p2 * 2.01f;
     f = f + 0.2500f * xor_noise(p0, p1, p2);
