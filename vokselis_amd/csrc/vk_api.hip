@@ -32,7 +32,7 @@ struct vk_ctx {
     void *vol = nullptr, *vol2 = nullptr;  // cells / dense voxels / pair
     void *scopy[3] = {nullptr, nullptr, nullptr};  // VK_LAYOUT_STAGED: one brick copy per slow axis
     StagedDesc sdesc{};
-    uint32_t stage_cap_bytes = 10240, stage_slab_cells = 8, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
+    uint32_t stage_cap_bytes = 0, stage_slab_cells = 8, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
     uint8_t *dist = nullptr;
     uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
     size_t vol_bytes = 0;
@@ -754,7 +754,10 @@ static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
 template <int VOL>
 static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     StagedDesc D = ctx->sdesc;
-    D.cap_bytes = std::min(std::max(ctx->stage_cap_bytes & ~15u, 1024u), 65536u);
+    // LDS window per wave: more LDS = thicker slabs but fewer waves per CU; measured optimum (tools/staged_sweep.py):
+    // 8 KiB for u8 (C5), 12 KiB for f16 (C4: at 10 KiB some waves at the far end fall back to single-step rounds)
+    const uint32_t cap_auto = VOL == VOL_S8U8 ? 8192u : 12288u;
+    D.cap_bytes = std::min(std::max((ctx->stage_cap_bytes ? ctx->stage_cap_bytes : cap_auto) & ~15u, 1024u), 65536u);
     D.slab_cells = std::min(std::max(ctx->stage_slab_cells, 1u), 32u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (f16) {

@@ -135,10 +135,10 @@ __device__ __forceinline__ float mix_lerp(float f, float d, uint32_t a) {
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(f), "v"(d), "v"(a));
     return r;
 }
-// a * b + c on 24-bit signed operands (window addressing)
+// a * b + c on 24-bit signed operands, b wave-uniform (window addressing: the row and slice pitches)
 __device__ __forceinline__ int mad_i24(int a, int b, int c) {
     int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
 
@@ -170,19 +170,18 @@ __device__ __forceinline__ float filter_pairs(const uint32_t lo[4], const uint32
             d[F] = e; d[M] = k & 1; d[S] = k >> 1;
             tp[d[0] + 2 * d[1] + 4 * d[2]] = e ? hi[k] : lo[k];
         }
-    float c[4];  // x edges at (dy, dz) = (0,0) (1,0) (0,1) (1,1)
+    // u8 taps take the f16 path too: the byte b, read as an f16 bit pattern, is the subnormal b * 2^-24, which
+    // v_fma_mix_f32 converts exactly.  The whole filter is linear, every intermediate stays in f32's normal range, and
+    // a power-of-two scale commutes with rounding: each value below is 2^-24 times the specified one, bit for bit, and
+    // the final constant folds the 2^24 back (f32(1/255) * 2^24 is exact).  Eight conversions per sample saved.
+    float dl[4], c[4];  // x edges at (dy, dz) = (0,0) (1,0) (0,1) (1,1); the four differences first: no back-to-back dependence
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if constexpr (U8) {
-            const float a = (float)tp[2 * j], b = (float)tp[2 * j + 1];
-            c[j] = fmaf(fx, b - a, a);
-        } else {
-            c[j] = mix_lerp(fx, mix_sub(tp[2 * j + 1], tp[2 * j]), tp[2 * j]);
-        }
-    }
+    for (int j = 0; j < 4; j++) dl[j] = mix_sub(tp[2 * j + 1], tp[2 * j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = mix_lerp(fx, dl[j], tp[2 * j]);
     const float c0 = fmaf(fy, c[1] - c[0], c[0]), c1 = fmaf(fy, c[3] - c[2], c[2]);
     float v = fmaf(fz, c1 - c0, c0);
-    if (U8) v = v * (1.0f / 255.0f);
+    if (U8) v = v * ((1.0f / 255.0f) * 16777216.0f);
     return v;
 }
 
