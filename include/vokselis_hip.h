@@ -145,9 +145,17 @@ int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t ti
  * (row-major; the reference's TILE_SIZE scheme, examples/xor/main.rs:12,77-95); this call
  * renders the tiles at positions q = rank + j*nranks of the heaviest-first order (vk_partition_order)
  * into `compact_out` (device memory, [n_slots][tile_size][tile_size] pixels of the backbuffer's
- * format, slot j <-> position rank + j*nranks).
+ * format, slot j <-> position rank + j*nranks; with vk_partition_root_skip the deal is the weighted one).
  * vk_partition_slots gives n_slots (identical on every rank, for a fixed-size gather). */
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots);
+/* A lighter share for the root.  Positions are dealt in rounds, one per rank and round; with root_skip = k >= 2 rank 0
+ * sits out every k-th round (its share is (k-1)/k of a peer's): rank 0 also receives and un-tiles every frame, and
+ * without this the other ranks wait for it.  0 (default): plain round robin.  Set the same value on every rank's
+ * context before partitioning; it applies to vk_render_partition, vk_render_batch, vk_untile(_batch) and
+ * vk_partition_active.  vk_partition_slots_weighted: the slot count (of a non-root rank) under that deal. */
+int vk_partition_root_skip(vk_ctx *ctx, uint32_t root_skip);
+int vk_partition_slots_weighted(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t root_skip,
+                                uint32_t *n_slots);
 int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                         float dt_scale, uint32_t flags, void *compact_out);
 /* The partition deals tiles heaviest-first (a launch/balance heuristic derived from the camera):

@@ -17,6 +17,31 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_weighted_deal_is_a_bijection():
+    """deal_pos / deal_owner (Python mirror of vk_kernels.hpp): every position has exactly one (rank, slot), slots are
+    dense per rank, the root's share shrinks to (k-1)/k of a peer's."""
+    from vokselis_amd import dist as D
+
+    for world in (1, 2, 3, 4, 8):
+        for k in (0, 2, 3, 5, 16):
+            if world == 1 and k:
+                continue
+            tiles = 510
+            seen = {}
+            for q in range(tiles):
+                r, sl = D.deal_owner(q, world, k)
+                assert 0 <= r < world and D.deal_pos(r, sl, world, k) == q
+                assert (r, sl) not in seen
+                seen[(r, sl)] = q
+            rounds = D.deal_rounds(tiles, world, k)
+            per_rank = [sorted(sl for (r, sl) in seen if r == rr) for rr in range(world)]
+            for rr in range(world):
+                assert per_rank[rr] == list(range(len(per_rank[rr]))) and len(per_rank[rr]) <= rounds
+            assert rounds - 1 <= max(len(p) for p in per_rank) <= rounds  # (the last round may hold the root's tile only)
+            if k >= 2 and world > 1:
+                assert abs(len(per_rank[0]) / len(per_rank[1]) - (k - 1) / k) < 0.05
+
+
 def _worker(rank, world, port, W, H, ts, q):
     import torch.distributed as dist
 
@@ -32,10 +57,11 @@ def _worker(rank, world, port, W, H, ts, q):
         dts = (1.0, 0.5, 0.75)  # a batch of three frames
         B = len(dts)
         tx, _ = D.tiles_xy(W, H, ts)
-        cap = D.n_slots(W, H, ts, world)
+        k = 3  # the root sits out every third round of the deal
+        cap = D.n_slots(W, H, ts, world, k)
         send = torch.zeros((cap, B, ts, ts, 4), dtype=torch.float32)
         for b, dt in enumerate(dts):
-            for j, t in enumerate(D.local_tiles(W, H, ts, rank, world)):
+            for j, t in enumerate(D.local_tiles(W, H, ts, rank, world, root_skip=k)):
                 x0, y0 = (t % tx) * ts, (t // tx) * ts
                 full, _, _ = O.render(cam, vol, W, H, dt_scale=dt, tile=(x0, y0, ts, ts), want_counts=False)
                 tile = full[y0:y0 + ts, x0:x0 + ts]
@@ -44,7 +70,7 @@ def _worker(rank, world, port, W, H, ts, q):
         recv = torch.zeros((world, cap, B, ts, ts, 4), dtype=torch.float32) if rank == 0 else None
         tg.gather(send, recv)
         if rank == 0:
-            frames = D.untile_batch_reference(recv.numpy(), W, H, ts)
+            frames = D.untile_batch_reference(recv.numpy(), W, H, ts, root_skip=k)
             for b, dt in enumerate(dts):
                 ref, _, _ = O.render(cam, vol, W, H, dt_scale=dt, want_counts=False)
                 q.put((b, float(np.abs(frames[b] - ref).max()), bool((frames[b] == ref).all())))

@@ -274,8 +274,9 @@ def test_render_batch_equals_single_frames(V, O):
             got = frames.cpu().numpy()
             for k in range(B):
                 assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), (name, "whole frames", k)
-            cap = V.partition_slots(W, H, ts, 1)
-            for nr in (1, 2, 3, 8):
+            for nr, k in ((1, 0), (2, 0), (3, 2), (8, 3), (8, 0), (2, 5)):
+                ctx.set_root_skip(k)
+                cap = V.partition_slots(W, H, ts, nr, k)
                 gathered = None
                 for r in range(nr):
                     buf = torch.zeros((cap, B, ts, ts, 4), dtype=tdt, device="cuda")
@@ -288,8 +289,9 @@ def test_render_batch_equals_single_frames(V, O):
                 V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
                 ctx.sync()
                 got = frames.cpu().numpy()
-                for k in range(B):
-                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), (name, "ranks", nr, k)
+                for j in range(B):
+                    assert (got[j].view(np.uint8) == singles[j].view(np.uint8)).all(), (name, "ranks", nr, "root_skip", k, j)
+            ctx.set_root_skip(0)
         finally:
             ctx.close()
     # error behaviour: counters are per frame, whole frames need one rank, capacity is checked

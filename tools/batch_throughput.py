@@ -26,12 +26,22 @@ for B in (2, 4, 8, 16, 32):
     frames = torch.empty((B, H, W, 4), dtype=torch.float16, device="cuda")
     ms = timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, frames.data_ptr(), tile_size=TS))
     print(json.dumps({"batch": B, "whole_frames_ms_per_frame": round(ms / B, 4)}))
-for B in (8, 16, 32):
+for B in (16, 32):
+    frames = torch.empty((B, H, W, 4), dtype=torch.float16, device="cuda")
     for nr in (1, 2, 4, 8):
-        buf = torch.empty((cap, B, TS, TS, 4), dtype=torch.float16, device="cuda")
-        worst = 0.0
-        for r in range(nr):
-            ms = timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=r, nranks=nr, compact=True, slot_capacity=cap))
-            worst = max(worst, ms)
-        print(json.dumps({"batch": B, "nranks": nr, "slowest_rank_ms_per_frame": round(worst / B, 4)}))
+        for k in ((0,) if nr == 1 else (0, 2, 3, 4, 6)):
+            ctx.set_root_skip(k)
+            capk = V.partition_slots(W, H, TS, nr, k)
+            buf = torch.empty((capk, B, TS, TS, 4), dtype=torch.float16, device="cuda")
+            gathered = torch.empty((nr, capk, B, TS, TS, 4), dtype=torch.float16, device="cuda")
+            per_rank = []
+            for r in range(nr):
+                per_rank.append(timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=r, nranks=nr, compact=True, slot_capacity=capk)))
+            bid, act = V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=0, nranks=nr, compact=True, slot_capacity=capk)
+            g2 = gathered[:, :act].contiguous()
+            un = timeit(lambda: V.untile_batch(ctx, bid, g2.data_ptr(), act, frames.data_ptr()))
+            root = per_rank[0] + un
+            print(json.dumps({"batch": B, "nranks": nr, "root_skip": k, "root_march+untile_us_per_frame": round(root / B * 1e3, 1), "untile_us_per_frame": round(un / B * 1e3, 1),
+                              "slowest_peer_us_per_frame": round(max(per_rank[1:] or [0]) / B * 1e3, 1), "bound_us_per_frame": round(max(root, max(per_rank)) / B * 1e3, 1)}))
+ctx.set_root_skip(0)
 ctx.close()

@@ -43,6 +43,8 @@ SYMBOLS = {
     "vk_backbuffer_clear": (C.c_int, [_vp]),
     "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
     "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "vk_partition_slots_weighted": (C.c_int, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "vk_partition_root_skip": (C.c_int, [_vp, _u32]),
     "vk_render_partition": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),
     "vk_partition_order": (C.c_int, [_vp, C.c_int, _u32, C.POINTER(_u32), _u32]),
     "vk_partition_active": (C.c_int, [_vp, C.c_int, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),

@@ -188,6 +188,10 @@ class Context:
     def sync(self):
         N.check(self._h, N.lib().vk_ctx_sync(self._h))
 
+    def set_root_skip(self, k: int):
+        """vk_partition_root_skip: rank 0 sits out every k-th round of the tile deal (0: never)."""
+        N.check(self._h, N.lib().vk_partition_root_skip(self._h, int(k)))
+
     def set_param(self, name: str, value: float):
         """Debug / tuning knob of the library (vk_debug_set_param)."""
         N.check(self._h, N.lib().vk_debug_set_param(self._h, name.encode(), float(value)))
@@ -358,9 +362,9 @@ def untile_batch(ctx: Context, batch_id: int, gathered_ptr: int, n_slots: int, o
     N.check(ctx.handle, N.lib().vk_untile_batch(ctx.handle, batch_id, C.c_void_p(gathered_ptr), n_slots, C.c_void_p(out_ptr)))
 
 
-def partition_slots(width: int, height: int, tile_size: int, nranks: int) -> int:
+def partition_slots(width: int, height: int, tile_size: int, nranks: int, root_skip: int = 0) -> int:
     n = C.c_uint32()
-    rc = N.lib().vk_partition_slots(width, height, tile_size, nranks, C.byref(n))
+    rc = N.lib().vk_partition_slots_weighted(width, height, tile_size, nranks, root_skip, C.byref(n))
     if rc != N.VK_OK:
         raise N.VokselisError(rc, "vk_partition_slots: bad arguments")
     return n.value

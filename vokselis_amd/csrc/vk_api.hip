@@ -81,9 +81,10 @@ struct vk_ctx {
         unsigned char *d = nullptr, *h = nullptr;
         size_t cap = 0;
         hipEvent_t ev = nullptr;
-        uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0;
+        uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0, root_skip = 0;
     } batch[4];
     uint32_t batch_seq = 0;
+    uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
 
     // present targets (next row N1/N2)
     uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
@@ -1081,7 +1082,8 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     }
     // a partition (compact output) covers only the active tiles; a plain render covers the whole region
     const uint64_t tiles = compact_out ? (uint64_t)ctx->order_active : (uint64_t)L.tiles_x * L.tiles_y;
-    const uint64_t slots = (tiles + nranks - 1) / nranks;
+    L.root_skip = nranks > 1 ? ctx->root_skip : 0u;
+    const uint64_t slots = deal_rounds((uint32_t)tiles, nranks, L.root_skip);
     L.n_tiles_launch = (uint32_t)tiles;
     if (tiles == 0) return VK_OK;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
@@ -1121,9 +1123,20 @@ int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t ti
 }
 
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots) {
-    if (!n_slots || tile_size == 0 || (tile_size & 7u) || nranks == 0 || width == 0 || height == 0) return VK_ERR_INVALID;
+    return vk_partition_slots_weighted(width, height, tile_size, nranks, 0, n_slots);
+}
+
+int vk_partition_slots_weighted(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t root_skip, uint32_t *n_slots) {
+    if (!n_slots || tile_size == 0 || (tile_size & 7u) || nranks == 0 || width == 0 || height == 0 || root_skip == 1) return VK_ERR_INVALID;
     uint64_t tiles = (uint64_t)((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
-    *n_slots = (uint32_t)((tiles + nranks - 1) / nranks);
+    *n_slots = deal_rounds((uint32_t)tiles, nranks, nranks > 1 ? root_skip : 0u);
+    return VK_OK;
+}
+
+int vk_partition_root_skip(vk_ctx *ctx, uint32_t root_skip) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (root_skip == 1) return fail(ctx, VK_ERR_INVALID, "vk_partition_root_skip: 0 (never) or >= 2 (rank 0 sits out every k-th round)");
+    ctx->root_skip = root_skip;
     return VK_OK;
 }
 
@@ -1145,7 +1158,7 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
     int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size, 1.0f);
     if (orc) return orc;
     if (n_active_tiles) *n_active_tiles = ctx->order_active;
-    if (n_active_slots) *n_active_slots = (ctx->order_active + nranks - 1) / nranks;
+    if (n_active_slots) *n_active_slots = deal_rounds(ctx->order_active, nranks, nranks > 1 ? ctx->root_skip : 0u);
     return VK_OK;
 }
 
@@ -1195,13 +1208,15 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
     if (owc) return owc;
     const uint32_t *d_pos = ctx->d_order_pos;
     const uint32_t n_active = ctx->order_active;
-    const uint64_t n = (uint64_t)ctx->width * ctx->height;
-    const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
+    const uint32_t chunks = (tile_size * tile_size + 511u) / 512u;
+    const uint64_t blocks = (uint64_t)n_tiles * chunks;
+    if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile: too many tiles for one launch");
+    const uint32_t rs = nranks > 1 ? ctx->root_skip : 0u;
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA16F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, d_pos, n_active);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active);
     else
-        hipLaunchKernelGGL(untile_kernel<OUT_RGBA32F>, dim3(blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, nranks, n_slots, d_pos, n_active);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active);
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
 }
@@ -1268,20 +1283,21 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         std::memcpy(h_pos + f * n_tiles, pos.data(), n_tiles * sizeof(uint32_t));
         max_active = std::max(max_active, n_active);
     }
-    const uint32_t slots_active = (max_active + nranks - 1) / nranks;
+    const uint32_t root_skip = nranks > 1 ? ctx->root_skip : 0u;
+    const uint32_t slots_active = deal_rounds(max_active, nranks, root_skip);
     if (n_active_slots) *n_active_slots = slots_active;
     const uint64_t slots = compact ? (uint64_t)slots_active : (uint64_t)n_tiles;
     if (compact && slots_active > slot_capacity) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: slot_capacity smaller than the active slots of this batch");
     HIP_TRY(ctx, hipMemcpyAsync(B.d, B.h, bytes, hipMemcpyHostToDevice, ctx->stream));
     B.id = ++ctx->batch_seq;
-    B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active;
+    B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active; B.root_skip = root_skip;
     if (batch_id) *batch_id = B.id;
     if (slots == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
     LaunchDesc L{};
     L.W = ctx->width; L.H = ctx->height;
     L.ox = 0; L.oy = 0; L.rw = ctx->width; L.rh = ctx->height;
     L.ts = ts; L.tiles_x = tx; L.tiles_y = ty;
-    L.rank = rank; L.nranks = nranks;
+    L.rank = rank; L.nranks = nranks; L.root_skip = root_skip;
     L.tile_order = reinterpret_cast<const uint32_t *>(B.d + (size_t)n_frames * sizeof(FrameDesc));
     L.n_tiles_launch = 0;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
@@ -1306,15 +1322,16 @@ int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32
     if (!B) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: that batch is no longer held (more than 3 batches ago)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t tx = (ctx->width + B->ts - 1) / B->ts;
-    const uint64_t n = (uint64_t)ctx->width * ctx->height * B->n_frames;
-    if ((n + 255) / 256 >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile_batch: too many pixels for one launch");
+    const uint32_t chunks = (B->ts * B->ts + 511u) / 512u;
+    const uint64_t blocks = (uint64_t)B->n_frames * B->n_tiles * chunks;
+    if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile_batch: too many tiles for one launch");
     const FrameDesc *frames = reinterpret_cast<const FrameDesc *>(B->d);
     const uint32_t *pos = reinterpret_cast<const uint32_t *>(B->d + (size_t)B->n_frames * sizeof(FrameDesc)) + (size_t)B->n_frames * B->n_tiles;
     // FrameDesc::n_active of a compact batch is the frame's active tile count (what the gather carried)
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u);
     else
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(B->ev, ctx->stream));
     return VK_OK;
@@ -1483,7 +1500,8 @@ int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *camera
         return rc ? gfail(root, rc) : VK_OK;
     }
     uint32_t cap = 0;
-    if (vk_partition_slots(root->width, root->height, tile_size, (uint32_t)n, &cap) != VK_OK) { g->err = "vk_group_render: bad tile size"; return VK_ERR_INVALID; }
+    if (vk_partition_slots_weighted(root->width, root->height, tile_size, (uint32_t)n, root->root_skip, &cap) != VK_OK) { g->err = "vk_group_render: bad tile size"; return VK_ERR_INVALID; }
+    for (int i = 1; i < n; i++) g->ctx[i]->root_skip = root->root_skip;  // one deal for the whole group
     const size_t tile_bytes = (size_t)tile_size * tile_size * px_bytes(root->out_format);
     const size_t need = (size_t)cap * n_frames * tile_bytes;
     if (g->send_bytes < need) {

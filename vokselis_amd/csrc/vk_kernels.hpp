@@ -85,6 +85,7 @@ struct LaunchDesc {
     uint32_t tiles_x, tiles_y;
     uint32_t n_tiles_launch;  // leading positions of the order this launch covers
     uint32_t rank, nranks;
+    uint32_t root_skip;  // dealing: rank 0 sits out every root_skip-th round (< 2: never)
     uint32_t n_blocks;   // logical 8x8 blocks of this launch
     uint32_t compact;    // 1: output is [slot][ts][ts], 0: [H][W]
     float dt_scale;
@@ -120,6 +121,32 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t b) {
 // (Dealing the tiles out SIMD by SIMD -- every SIMD one block from each of 8 tiles -- left the per-SIMD work
 // spread at max/mean 1.66: the spread is block-to-block variation inside tiles, not tile placement.
 // tools/experiments/simd_interleaved_block_order.patch)
+
+// ---- dealing positions of the heaviest-first order to ranks ------------------------------------
+// Round j gives one position to every rank, in rank order.  With root_skip = k >= 2 the root (rank 0) sits out every
+// k-th round (rounds k-1, 2k-1, ...): it also un-tiles every frame, and a lighter share of the march keeps it from
+// being the rank everybody waits for.  k < 2: plain round robin, position q -> rank q % N, slot q / N.
+__host__ __device__ __forceinline__ uint32_t deal_pos(uint32_t rank, uint32_t slot, uint32_t N, uint32_t k) {
+    if (k < 2u) return rank + slot * N;
+    const uint32_t round = rank ? slot : slot + slot / (k - 1u);  // the root's slot j is its j-th full round
+    const uint32_t start = round * N - round / k;                 // one position less for every light round before
+    return start + rank - ((round % k) == k - 1u ? 1u : 0u);      // (the root never sees a light round)
+}
+__host__ __device__ __forceinline__ void deal_owner(uint32_t pos, uint32_t N, uint32_t k, uint32_t &rank, uint32_t &slot) {
+    if (k < 2u) { rank = pos % N; slot = pos / N; return; }
+    const uint32_t G = k * N - 1u, g = pos / G, o = pos - g * G;  // a group: k - 1 full rounds and a light one
+    uint32_t rj;
+    if (o < (k - 1u) * N) { rj = o / N; rank = o - rj * N; }
+    else { rj = k - 1u; rank = o - (k - 1u) * N + 1u; }
+    slot = rank ? g * k + rj : g * (k - 1u) + rj;
+}
+// rounds needed to deal `tiles` positions = slots of a non-root rank
+__host__ __device__ __forceinline__ uint32_t deal_rounds(uint32_t tiles, uint32_t N, uint32_t k) {
+    if (k < 2u) return (tiles + N - 1u) / N;
+    uint32_t r = tiles / N;
+    while (r * N - r / k < tiles) r++;
+    return r;
+}
 
 struct PixelMap {
     int32_t x, y;      // image coordinates
@@ -174,7 +201,7 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameVi
     uint32_t sps = L.ts >> 3;              // 8x8 blocks per tile edge
     uint32_t per_tile = sps * sps;
     uint32_t slot = lb / per_tile, sub = lb - slot * per_tile;
-    uint32_t pos = L.rank + slot * L.nranks;  // position in the heaviest-first order
+    uint32_t pos = deal_pos(L.rank, slot, L.nranks, L.root_skip);  // position in the heaviest-first order
     const uint32_t n_tiles = L.tiles_x * L.tiles_y;
     uint32_t tile = pos < fv.n_tiles_launch ? fv.order[pos] : n_tiles;
     uint32_t tty = tile / L.tiles_x, ttx = tile - tty * L.tiles_x;
@@ -1598,47 +1625,56 @@ __global__ __launch_bounds__(256) void present_kernel(const void *__restrict__ b
     if (bgra8) bgra8[id] = b | (g << 8) | (r << 16) | (al << 24);
 }
 
-// Root side of the multi-GPU frame: gathered [nranks][n_slots][ts][ts] -> [H][W]
-template <int OUT>
-__global__ __launch_bounds__(256) void untile_kernel(const void *__restrict__ gathered, void *__restrict__ out,
-                                                     uint32_t W, uint32_t H, uint32_t ts, uint32_t tiles_x,
-                                                     uint32_t nranks, uint32_t n_slots,
-                                                     const uint32_t *__restrict__ tile_pos, uint32_t n_active) {
-    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (uint64_t)W * H) return;
-    uint32_t x = (uint32_t)(id % W), y = (uint32_t)(id / W);
-    uint32_t pos = tile_pos[(y / ts) * tiles_x + (x / ts)];  // tile id -> position in the order
-    if (pos >= n_active) {  // tile outside the cube's screen rectangle: never marched, never gathered
-        store_pixel<OUT>(out, id, 0.0f, 0.0f, 0.0f, 1.0f);
-        return;
-    }
-    uint32_t rank = pos % nranks, slot = pos / nranks;
-    size_t src = (((size_t)rank * n_slots + slot) * ts + (y % ts)) * ts + (x % ts);
-    if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];
-    else reinterpret_cast<uint2 *>(out)[id] = reinterpret_cast<const uint2 *>(gathered)[src];
-}
-
 // Root side of a batched multi-GPU launch: gathered [nranks][slot][frame][ts][ts] (slot < n_slots) -> frames [B][H][W].
-// tables: per frame, the inverse order (tile id -> position) at tables[pos_off + frame * n_tiles].
+// tile_pos: per frame, the inverse order (tile id -> position) at tile_pos[frame * n_tiles + tile].
+// One workgroup moves 512 pixels of one tile, two adjacent pixels (16 / 32 bytes) per lane: the tile's owner and
+// source base are wave-uniform, loads and stores are whole 16-byte vectors (the per-pixel form of round 1 reached
+// 2 TB/s; this is the copy the root pays for every frame).  frames == nullptr: one frame with n_active_one active tiles
+// (vk_untile).
 template <int OUT>
 __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restrict__ gathered, void *__restrict__ out, uint32_t W, uint32_t H, uint32_t ts,
                                                            uint32_t tiles_x, uint32_t n_tiles, uint32_t nranks, uint32_t n_slots, uint32_t n_frames,
-                                                           const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames) {
-    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t npx = (uint64_t)W * H;
-    if (id >= npx * n_frames) return;
-    const uint32_t frame = (uint32_t)(id / npx);
-    const uint32_t px = (uint32_t)(id - (uint64_t)frame * npx);
-    const uint32_t x = px % W, y = px / W;
-    const uint32_t pos = tile_pos[(size_t)frame * n_tiles + (y / ts) * tiles_x + (x / ts)];
-    if (pos >= frames[frame].n_active) {  // outside the cube's screen rectangle: never marched, never gathered
-        store_pixel<OUT>(out, id, 0.0f, 0.0f, 0.0f, 1.0f);
+                                                           const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames, uint32_t root_skip,
+                                                           uint32_t n_active_one) {
+    const uint32_t chunks = (ts * ts + 511u) / 512u;  // 512-pixel chunks per tile
+    uint32_t b = blockIdx.x;
+    const uint32_t chunk = b % chunks; b /= chunks;
+    const uint32_t tile = b % n_tiles;
+    const uint32_t frame = b / n_tiles;
+    if (frame >= n_frames) return;
+    const uint32_t l = chunk * 512u + threadIdx.x * 2u;  // first of this lane's two pixels inside the tile (ts is even)
+    if (l >= ts * ts) return;
+    const uint32_t ly = l / ts, lx = l - ly * ts;
+    const uint32_t tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const uint32_t x = txi * ts + lx, y = tyi * ts + ly;
+    if (x >= W || y >= H) return;
+    const bool two = x + 1u < W;  // W odd: the last pixel of a row stands alone
+    const size_t dst = ((size_t)frame * H + y) * W + x;
+    const uint32_t pos = tile_pos[(size_t)frame * n_tiles + tile];
+    const uint32_t n_active = frames ? frames[frame].n_active : n_active_one;
+    if (pos >= n_active) {  // outside the cube's screen rectangle: never marched, never gathered
+        store_pixel<OUT>(out, dst, 0.0f, 0.0f, 0.0f, 1.0f);
+        if (two) store_pixel<OUT>(out, dst + 1, 0.0f, 0.0f, 0.0f, 1.0f);
         return;
     }
-    const uint32_t rank = pos % nranks, slot = pos / nranks;
-    const size_t src = ((((size_t)rank * n_slots + slot) * n_frames + frame) * ts + (y % ts)) * ts + (x % ts);
-    if (OUT == OUT_RGBA32F) reinterpret_cast<float4 *>(out)[id] = reinterpret_cast<const float4 *>(gathered)[src];
-    else reinterpret_cast<uint2 *>(out)[id] = reinterpret_cast<const uint2 *>(gathered)[src];
+    uint32_t rank, slot;
+    deal_owner(pos, nranks, root_skip, rank, slot);
+    const size_t src = ((((size_t)rank * n_slots + slot) * n_frames + frame) * ts + ly) * ts + lx;
+    if (OUT == OUT_RGBA32F) {
+        const float4 *g = reinterpret_cast<const float4 *>(gathered);
+        float4 *o = reinterpret_cast<float4 *>(out);
+        o[dst] = g[src];
+        if (two) o[dst + 1] = g[src + 1];
+    } else {
+        const uint2 *g = reinterpret_cast<const uint2 *>(gathered);
+        uint2 *o = reinterpret_cast<uint2 *>(out);
+        if (two && ((dst & 1u) == 0u)) {  // src is even (ts, lx even): one 16-byte load, one 16-byte store
+            *reinterpret_cast<uint4 *>(o + dst) = *reinterpret_cast<const uint4 *>(g + src);
+        } else {
+            o[dst] = g[src];
+            if (two) o[dst + 1] = g[src + 1];
+        }
+    }
 }
 
 }  // namespace vk

@@ -28,22 +28,61 @@ def tiles_xy(width: int, height: int, tile_size: int):
     return (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
 
 
-def tile_owner(pos: int, world: int) -> int:
+def deal_pos(rank: int, slot: int, world: int, root_skip: int = 0) -> int:
+    """Position of the tile order that (rank, slot) marches.  Rounds give one position to every rank; with
+    root_skip = k >= 2 rank 0 sits out every k-th round (vk_partition_root_skip; deal_pos of vk_kernels.hpp)."""
+    k = root_skip
+    if k < 2:
+        return rank + slot * world
+    rnd = slot if rank else slot + slot // (k - 1)
+    return rnd * world - rnd // k + rank - (1 if rnd % k == k - 1 else 0)
+
+
+def deal_owner(pos: int, world: int, root_skip: int = 0):
+    """(rank, slot) owning position `pos` (the inverse of deal_pos)."""
+    k = root_skip
+    if k < 2:
+        return pos % world, pos // world
+    G = k * world - 1
+    g, o = divmod(pos, G)
+    if o < (k - 1) * world:
+        rj, rank = divmod(o, world)
+    else:
+        rj, rank = k - 1, o - (k - 1) * world + 1
+    return rank, (g * k + rj if rank else g * (k - 1) + rj)
+
+
+def deal_rounds(tiles: int, world: int, root_skip: int = 0) -> int:
+    """Rounds needed to deal `tiles` positions = slots of a non-root rank."""
+    k = root_skip
+    if k < 2:
+        return (tiles + world - 1) // world
+    r = tiles // world
+    while r * world - r // k < tiles:
+        r += 1
+    return r
+
+
+def tile_owner(pos: int, world: int, root_skip: int = 0) -> int:
     """Rank owning position `pos` of the tile order."""
-    return pos % world
+    return deal_owner(pos, world, root_skip)[0]
 
 
-def local_tiles(width: int, height: int, tile_size: int, rank: int, world: int, order=None):
-    """Row-major tile ids of this rank in slot order: slot j <-> position rank + j*world of `order`
-    (the library's heaviest-first order, `Context.partition_order`; identity when None)."""
+def local_tiles(width: int, height: int, tile_size: int, rank: int, world: int, order=None, root_skip: int = 0):
+    """Row-major tile ids of this rank in slot order (`order`: the library's heaviest-first order,
+    `Context.partition_order`; identity when None)."""
     tx, ty = tiles_xy(width, height, tile_size)
-    pos = range(rank, tx * ty, world)
-    return list(pos) if order is None else [int(order[q]) for q in pos]
+    out = []
+    for slot in range(deal_rounds(tx * ty, world, root_skip)):
+        q = deal_pos(rank, slot, world, root_skip)
+        if q < tx * ty and deal_owner(q, world, root_skip) == (rank, slot):
+            out.append(q if order is None else int(order[q]))
+    return out
 
 
-def n_slots(width: int, height: int, tile_size: int, world: int) -> int:
+def n_slots(width: int, height: int, tile_size: int, world: int, root_skip: int = 0) -> int:
     tx, ty = tiles_xy(width, height, tile_size)
-    return (tx * ty + world - 1) // world
+    return deal_rounds(tx * ty, world, root_skip)
 
 
 class TorchTileGather:
@@ -79,7 +118,7 @@ class BatchTileRenderer:
     next-but-one batch is launched).  flush() launches a partial batch and drains."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, batch: int = 16, root: int = 0, group=None,
-                 transport: str = "rccl", on_batch=None, via_host: bool = False):
+                 transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto"):
         import torch
         import torch.distributed as dist
 
@@ -92,7 +131,7 @@ class BatchTileRenderer:
         self.dtype = torch.float32 if bb.format == N.OUT_RGBA32F else torch.float16
         self.esize = 4 if bb.format == N.OUT_RGBA32F else 2
         self.dev = torch.device("cuda", torch.cuda.current_device())
-        self.cap = partition_slots(self.W, self.H, tile_size, self.world)
+        self._group = group
         # the march runs on torch's current stream (handle 0, the legacy default stream, reads as "the context's own")
         cur = torch.cuda.current_stream()
         if not cur.cuda_stream:
@@ -116,6 +155,11 @@ class BatchTileRenderer:
             self.tg = TorchTileGather(group, root, via_host)
         else:
             raise ValueError("transport is 'rccl' or 'torch'")
+        # The root also receives and un-tiles every frame: give it a lighter share of the march (rank 0 sits out every
+        # k-th round of the deal).  "auto": k from this GPU's own timings of one batch's march and un-tile.
+        self.root_skip = self._calibrate_root_skip() if root_skip == "auto" else int(root_skip)
+        ctx.set_root_skip(self.root_skip if self.world > 1 else 0)
+        self.cap = partition_slots(self.W, self.H, tile_size, self.world, self.root_skip if self.world > 1 else 0)
         shape = (self.cap, self.batch, tile_size, tile_size, 4)
         self.send = [torch.zeros(shape, dtype=self.dtype, device=self.dev) for _ in range(2)]
         self.recv = self.frames = None
@@ -132,6 +176,38 @@ class BatchTileRenderer:
     @property
     def is_root(self) -> bool:
         return self.rank == self.root
+
+    def _calibrate_root_skip(self) -> int:
+        """k = (M + U) / (U * world) balances the root's march share + un-tile against a peer's share, with M the time
+        to march one whole frame's tiles and U the time to un-tile one frame, both measured here on a 4-frame batch."""
+        import torch.distributed as dist
+
+        torch = self.torch
+        if self.world == 1 or self.root != 0:  # (uniform over the ranks: everybody joins the broadcast below)
+            return 0
+        k = [0]
+        if self.is_root and self.ctx.camera_blob is not None:
+            B = min(4, self.batch)
+            cap1 = partition_slots(self.W, self.H, self.ts, 1)
+            tiles = torch.zeros((cap1, B, self.ts, self.ts, 4), dtype=self.dtype, device=self.dev)
+            frames = torch.zeros((B, self.H, self.W, 4), dtype=self.dtype, device=self.dev)
+            cams = [self.ctx.camera_blob] * B
+            self.ctx.set_root_skip(0)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for it in range(2):  # the second pass is the measurement
+                ev[0].record()
+                bid, act = render_batch(self.ctx, self.pipe, cams, tiles.data_ptr(), tile_size=self.ts, rank=0, nranks=1, compact=True, slot_capacity=cap1)
+                ev[1].record()
+                untile_batch(self.ctx, bid, tiles.data_ptr(), act, frames.data_ptr())
+                ev[2].record()
+                torch.cuda.current_stream().synchronize()
+            m, u = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+            if u > 0 and m > 0:
+                kk = int(round((m + u) / (u * self.world)))
+                k[0] = 0 if kk > 64 else max(2, kk)
+            del tiles, frames
+        dist.broadcast_object_list(k, src=self.root, group=self._group)
+        return int(k[0])
 
     def submit(self, camera_blob: bytes | None = None):
         blob = camera_blob if camera_blob is not None else self.ctx.camera_blob
@@ -199,7 +275,7 @@ class BatchTileRenderer:
             N.check(self.ctx.handle, N.lib().vk_comm_destroy(self.ctx.handle))
 
 
-def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None, n_active=None) -> np.ndarray:
+def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None, n_active=None, root_skip: int = 0) -> np.ndarray:
     """numpy statement of vk_untile: [world, n_slots, ts, ts, C] -> [H, W, C]; tiles at positions
     >= n_active of the order are clear colour (0,0,0,1)."""
     world = gathered.shape[0]
@@ -213,12 +289,13 @@ def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: i
             if n_active is not None and q >= n_active:
                 out[y0:y0 + h, x0:x0 + w] = [0, 0, 0, 1][: out.shape[-1]]
             else:
-                out[y0:y0 + h, x0:x0 + w] = gathered[q % world, q // world, :h, :w]
+                r, sl = deal_owner(q, world, root_skip)
+                out[y0:y0 + h, x0:x0 + w] = gathered[r, sl, :h, :w]
     return out
 
 
-def untile_batch_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, orders=None, n_active=None) -> np.ndarray:
+def untile_batch_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, orders=None, n_active=None, root_skip: int = 0) -> np.ndarray:
     """numpy statement of vk_untile_batch: [world, n_slots, B, ts, ts, C] -> [B, H, W, C] (per-frame orders / active counts)."""
     B = gathered.shape[2]
     return np.stack([untile_reference(gathered[:, :, b], width, height, tile_size, None if orders is None else orders[b],
-                                      None if n_active is None else n_active[b]) for b in range(B)])
+                                      None if n_active is None else n_active[b], root_skip) for b in range(B)])
