@@ -149,7 +149,7 @@ def make_volume(V, ctx, cfg, layout):
     return time.perf_counter() - t0
 
 
-def big_config_extra(V, torch, local_rank, key, frames=3):
+def big_config_extra(V, torch, local_rank, key, frames=6):
     """One BASELINE config on this GPU, single-frame launches: set-up time, step counts, launch time, roofline fraction."""
     cfg = CONFIGS[key]
     W, H = cfg["W"], cfg["H"]
@@ -160,7 +160,7 @@ def big_config_extra(V, torch, local_rank, key, frames=3):
         ctx.update()
         s_ref, s_samp = count_steps(ctx, V, 0)
         p = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE)
-        ms = time_launches(ctx, lambda: p.record(ctx), frames, warm=1)
+        ms = time_launches(ctx, lambda: p.record(ctx), frames, warm=2)
         alg = s_samp * cfg["b_step"] + W * H * B_RAY
         gb = alg / (ms * 1e-3) / 1e9
         dims = (V.native.C.c_uint32 * 3)()

@@ -916,19 +916,19 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                 // Adaptive probing (wave-uniform policy, any policy is exact: a sampled empty cell adds +0).  Probe for a
                 // window of 16 trips; if fewer than 1 in 8 of the wave's live rays skipped anything in it, the wave is in
                 // material that cannot be skipped: run the dense loop -- no distance look-up, and on the fast path
-                // software-pipelined -- for a stretch that doubles every time the next window confirms it (32 .. 256
-                // trips), then probe again.  Fog pays ~6 % of its trips at the probing price instead of all of them.
-                uint32_t stretch = 32;
+                // software-pipelined -- for a stretch that doubles every time the next window confirms it (64 .. 512
+                // trips), then probe again.  Fog pays ~9 % of its trips at the probing price instead of all of them.
+                uint32_t stretch = 64;
                 for (;;) {
                     cs.skips = 0;
                     bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr);
                     const unsigned long long live = __ballot(alive);
                     if (live == 0ull) break;
-                    if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = 32; continue; }
+                    if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = 64; continue; }
                     if constexpr (USE_LUT) alive = march_stream<VOL, COUNT, true>(V, r, cs, cell_lut, stretch);
                     else alive = march<VOL, false, SAFE, COUNT, true>(V, r, stretch, cs, nullptr);
                     if (__ballot(alive) == 0ull) break;
-                    stretch = min(stretch * 2u, 256u);
+                    stretch = min(stretch * 2u, 512u);
                 }
             } else {
                 march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
