@@ -176,3 +176,15 @@ def test_camera_blob_is_byte_identical_across_hosts(O, tmp_path):
     cpp = out.read_bytes()
     assert len(cpp) == 144 * len(orbits)
     assert [cpp[144 * i:144 * (i + 1)] for i in range(len(orbits))] == py
+
+
+def test_integration_md_lists_every_entry_point():
+    """INTEGRATION.md's Rust `extern "C"` block binds every function include/vokselis_hip.h declares (round 1's block
+    omitted present, capture, partition and group entry points)."""
+    hdr = open(os.path.join(ROOT, "include", "vokselis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", hdr))
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index('extern "C" {'):md.index("fn check(")]
+    bound = set(re.findall(r"pub fn (vk_[a-z0-9_]+)\(", block))
+    assert bound == declared, bound ^ declared
