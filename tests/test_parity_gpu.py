@@ -554,6 +554,28 @@ def test_staged_bricks_equal_linear_bitwise(V, O, golden_volumes):
     assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all()
 
 
+def test_staged_fuzz_dims_cameras_dt(V, O):
+    """Seeded fuzz of the staged layout: volume dims that are no multiple of the 8-voxel brick (padding, partial pieces,
+    the u8 copy's 16-voxel pieces), anisotropic, down to 3 voxels; cameras anywhere around and inside; dt from 0.11 to
+    2.3; default and small LDS budgets.  Frames and trip counts bitwise equal to the dense linear kernel."""
+    rng = np.random.default_rng(20261004)
+    W, H = 72, 56
+    for case in range(24):
+        dims = tuple(int(v) for v in rng.choice([3, 5, 9, 17, 23, 31, 37, 50, 64], 3))  # (nx, ny, nz)
+        f16 = bool(case & 1)
+        vol = O.volume_fog_f16(dims, seed=100 + case) if f16 else O.volume_standin_u8(dims)
+        if case % 5 == 0 and not f16:
+            vol = O.volume_fog_u8(dims, seed=7 + case, lo=18, span=30)
+        cam = O.camera_blob(float(rng.uniform(0.2, 3.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-6.0, 6.0)),
+                            tuple(float(v) for v in rng.uniform(0.2, 0.8, 3)), W / H)
+        dt = float(rng.choice([0.11, 0.37, 0.5, 1.0, 2.3]))
+        params = (("stage_cap_bytes", 2048),) if case % 3 == 0 else ()
+        ref, rsteps, _ = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_LINEAR)
+        img, steps, _ = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_STAGED, params)
+        assert (steps == rsteps).all(), (case, dims, dt)
+        assert (img.view(np.uint32) == ref.view(np.uint32)).all(), (case, dims, dt)
+
+
 def test_device_fog_generator_is_bit_identical(V, O):
     cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
     for fmt, host in ((V.FMT_R8_UNORM, O.volume_fog_u8((40, 24, 56), seed=99, lo=20, span=12)),

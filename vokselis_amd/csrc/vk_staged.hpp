@@ -48,27 +48,46 @@ __device__ const uint32_t kStageMagic[65] = {
     87652394u, 85899346u, 84215046u, 82595525u, 81037119u, 79536432u, 78090315u, 76695845u, 75350304u, 74051161u, 72796056u, 71582789u, 70409300u,
     69273667u, 68174085u, 67108865u};
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_take(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+// Wave-wide minimum / maximum by DPP, all 64 lanes active; the results are wave-uniform (read from lane 63).
+// Written as fused v_min/v_max_i32_dpp: from C++ the compiler emits v_mov + s_nop + v_mov_dpp + v_min per stage
+// (25 issue slots per reduction; a round makes five).  A DPP operand written by the previous VALU instruction needs two
+// wait states: the single form pays them as s_nop, the four-way form interleaves four independent reductions so that
+// every dependent pair is four instructions apart.
+#define VK_DPP_STAGES(OP, R)                                                             \
+    OP " %" #R ", %" #R ", %" #R " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+    OP " %" #R ", %" #R ", %" #R " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+    OP " %" #R ", %" #R ", %" #R " row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+    OP " %" #R ", %" #R ", %" #R " row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"          \
+    OP " %" #R ", %" #R ", %" #R " row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"        \
+    OP " %" #R ", %" #R ", %" #R " row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1\n\t"
 
-// Wave-wide minimum / maximum, all 64 lanes active; the result is wave-uniform (read from lane 63).
 __device__ __forceinline__ int wave_min_i32(int v) {
-    v = min(v, dpp_take<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
-    v = min(v, dpp_take<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
-    v = min(v, dpp_take<0x141, 0xF>(v));  // row_half_mirror
-    v = min(v, dpp_take<0x140, 0xF>(v));  // row_mirror: every lane of a row holds the row's minimum
-    v = min(v, dpp_take<0x142, 0xA>(v));  // row_bcast:15 -> rows 1, 3
-    v = min(v, dpp_take<0x143, 0xC>(v));  // row_bcast:31 -> rows 2, 3
-    return __builtin_amdgcn_readlane(v, 63);
+    int r;
+    asm volatile("s_nop 1\n\t" VK_DPP_STAGES("v_min_i32_dpp", 1) "v_readlane_b32 %0, %1, 63" : "=s"(r), "+v"(v));
+    return __builtin_amdgcn_readfirstlane(r);  // (an asm with a vector output counts as divergent: re-assert that r is wave-uniform)
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-    v = max(v, dpp_take<0xB1, 0xF>(v));
-    v = max(v, dpp_take<0x4E, 0xF>(v));
-    v = max(v, dpp_take<0x141, 0xF>(v));
-    v = max(v, dpp_take<0x140, 0xF>(v));
-    v = max(v, dpp_take<0x142, 0xA>(v));
-    v = max(v, dpp_take<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
+    int r;
+    asm volatile("s_nop 1\n\t" VK_DPP_STAGES("v_max_i32_dpp", 1) "v_readlane_b32 %0, %1, 63" : "=s"(r), "+v"(v));
+    return __builtin_amdgcn_readfirstlane(r);
+}
+#define VK_DPP4(CTRL)                                              \
+    "v_min_i32_dpp %4, %4, %4 " CTRL "\n\tv_max_i32_dpp %5, %5, %5 " CTRL "\n\t" \
+    "v_min_i32_dpp %6, %6, %6 " CTRL "\n\tv_max_i32_dpp %7, %7, %7 " CTRL "\n\t"
+// (min a, max b, min c, max d) over the wave, interleaved
+__device__ __forceinline__ void wave_minmax4(int a, int b, int c, int d, int &ra, int &rb, int &rc, int &rd) {
+    asm volatile("s_nop 1\n\t"
+                 VK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 VK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 VK_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 VK_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                 VK_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 VK_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n\t"
+                 "v_readlane_b32 %0, %4, 63\n\tv_readlane_b32 %1, %5, 63\n\tv_readlane_b32 %2, %6, 63\n\tv_readlane_b32 %3, %7, 63"
+                 : "=s"(ra), "=s"(rb), "=s"(rc), "=s"(rd), "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    ra = __builtin_amdgcn_readfirstlane(ra); rb = __builtin_amdgcn_readfirstlane(rb);  // wave-uniform, see wave_min_i32
+    rc = __builtin_amdgcn_readfirstlane(rc); rd = __builtin_amdgcn_readfirstlane(rd);
 }
 
 // Dense voxels -> one staged copy.  One thread per 16-byte piece, pieces enumerated in storage order.
@@ -266,8 +285,9 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         const float eM = fmaf(e, ratM, uM), eF = fmaf(e, ratF, uF);
         const int kMl = cvt_floor_i32(fminf(uM, eM) * 64.0f), kMh = cvt_floor_i32(fmaxf(uM, eM) * 64.0f);
         const int kFl = cvt_floor_i32(fminf(uF, eF) * 64.0f), kFh = cvt_floor_i32(fmaxf(uF, eF) * 64.0f);
-        const int bMl = wave_min_i32(inslab ? kMl : 0x7fffffff) - 2, bMh = wave_max_i32(inslab ? kMh : (int)0x80000000) + 3;
-        const int bFl = wave_min_i32(inslab ? kFl : 0x7fffffff) - 2, bFh = wave_max_i32(inslab ? kFh : (int)0x80000000) + 3;
+        int bMl, bMh, bFl, bFh;
+        wave_minmax4(inslab ? kMl : 0x7fffffff, inslab ? kMh : (int)0x80000000, inslab ? kFl : 0x7fffffff, inslab ? kFh : (int)0x80000000, bMl, bMh, bFl, bFh);
+        bMl -= 2; bMh += 3; bFl -= 2; bFh += 3;
         const int ilM = min(max((bMl >> 6) + kStagePad, 0), nvm1[M]), ihM = min(max((bMh >> 6) + kStagePad + 1, 0), nvm1[M]);  // + 1: the upper tap
         const int ilF = min(max((bFl >> 6) + kStagePad, 0), nvm1[F]), ihF = min(max((bFh >> 6) + kStagePad + 1, 0), nvm1[F]);
         const uint32_t pf0 = (uint32_t)ilF >> VSH, Efp = ((uint32_t)ihF >> VSH) - pf0 + 1u, Em = (uint32_t)(ihM - ilM) + 1u;
