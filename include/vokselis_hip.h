@@ -254,7 +254,7 @@ int vk_simt_census(vk_ctx *ctx, uint64_t out[4]);
 /* Debug: override the tile order table (experiments on launch order). */
 int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n);
 int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks);
-/* Debug / tuning knobs of the staged march: "stage_cap_bytes" (LDS window per wave; 0 = default: 8192 for u8, 12288 for f16),
+/* Debug / tuning knobs of the staged march: "stage_cap_bytes" (LDS window per wave; 0 = default: 8192 for u8, 10240 for f16),
  * "stage_slab_cells" (a round is a slab of at most that many cells along the wave's major axis, default 8), "stage_copies_mask" (bit k: build the brick copy
  * whose slow axis is k; applies to the next upload, default 7). */
 int vk_debug_set_param(vk_ctx *ctx, const char *name, double value);

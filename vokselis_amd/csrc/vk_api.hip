@@ -756,8 +756,9 @@ template <int VOL>
 static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     StagedDesc D = ctx->sdesc;
     // LDS window per wave: more LDS = thicker slabs but fewer waves per CU; measured optimum (tools/staged_sweep.py):
-    // 8 KiB for u8 (C5), 12 KiB for f16 (C4: at 10 KiB some waves at the far end fall back to single-step rounds)
-    const uint32_t cap_auto = VOL == VOL_S8U8 ? 8192u : 12288u;
+    // 8 KiB for u8 (C5), 10 KiB for f16 (C4: 2.30 ms against 2.39 at 12 KiB; 0.1 % of its rounds, at the far end, then
+    // fall back to one-cell slabs served from global memory)
+    const uint32_t cap_auto = VOL == VOL_S8U8 ? 8192u : 10240u;
     D.cap_bytes = std::min(std::max((ctx->stage_cap_bytes ? ctx->stage_cap_bytes : cap_auto) & ~15u, 1024u), 65536u);
     D.slab_cells = std::min(std::max(ctx->stage_slab_cells, 1u), 32u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
