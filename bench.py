@@ -163,11 +163,19 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ms = time_launches(ctx, lambda: p.record(ctx), frames, warm=2)
         alg = s_samp * cfg["b_step"] + W * H * B_RAY
         gb = alg / (ms * 1e-3) / 1e9
+        # the same frames several per launch (vk_render_batch), as the headline is run: a single launch of a few rounds of
+        # LDS-limited waves loses its tail
+        nb = 4 if key == "c4" else 2
+        fr = torch.empty((nb, H, W, 4), dtype=torch.float16, device="cuda")
+        blob = cam.get_proj_view_matrix()
+        ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, [blob] * nb, fr.data_ptr(), tile_size=TILE), 3, warm=1) / nb
+        del fr
         dims = (V.native.C.c_uint32 * 3)()
         lay, nbytes = V.native.C.c_int(), V.native.C.c_size_t()
         V.native.check(ctx.handle, V.native.lib().vk_volume_info(ctx.handle, dims, None, V.native.C.byref(lay), V.native.C.byref(nbytes)))
         return {"workload": cfg["name"], "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
                 "algorithmic_bytes_per_launch": alg, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS, "volume_setup_s": setup,
+                "batch": {"frames_per_launch": nb, "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
                 "volume_device_bytes": nbytes.value, "kernel": "vk::raymarch_staged_kernel" if lay.value == 6 else "vk::raymarch_naive_kernel"}
     finally:
@@ -346,12 +354,15 @@ def main():
                     except Exception:
                         pass
             else:
-                # N > 1: the per-rank launch, the gather and the un-tile overlap; the roofline is defined on a kernel's own
-                # duration and is reported by the N = 1 line
-                out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                                   "note": "per-kernel figure: see the N = 1 line; here march, gather and un-tile of different batches overlap",
-                                   "whole_job_algorithmic_GBps": alg_frame * args.steps / elapsed / 1e9}
+                # N > 1 (and --force-dist): march, gather and un-tile of different batches overlap on every rank, so no single
+                # kernel duration describes a step; the figure here is the whole job's algorithmic bytes over the wall time
+                # against N GPUs' HBM.  The per-kernel roofline is the N = 1 line's.
+                agg = alg_frame * args.steps / elapsed / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": agg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": agg / (HBM_PEAK_GBS * world), "traffic": None,
+                                   "kernel": "whole job (vk::raymarch_naive_kernel per rank + RCCL gather + un-tile, overlapped)",
+                                   "note": "aggregate over %d GPU(s): algorithmic bytes of K frames / wall time; per-kernel figure: see the N = 1 line" % world}
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
+                out["config"]["root_skip"] = btr.root_skip
 
         # untimed side measurements (rank 0, N = 1)
         if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
