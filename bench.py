@@ -397,17 +397,16 @@ def main():
                     gb = (ss * cfg["b_step"] + W * H * B_RAY) / (ms * 1e-3) / 1e9
                     extras[f"{name}_{mode}"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
-                if name == "fog":
-                    # the sampling loop with every step fetching its taps, batched like the headline
-                    try:
-                        fr = torch.empty((8, H, W, 4), dtype=torch.float16, device="cuda")
-                        ms = time_launches(ctx, lambda: V.render_batch(ctx, p_ns, [blob] * 8, fr.data_ptr(), tile_size=TILE), 10)
-                        sr, ss = extras["fog_noskip"]["s_ref"], extras["fog_noskip"]["s_sampled"]
-                        gb = (ss * cfg["b_step"] + W * H * B_RAY) * 8 / (ms * 1e-3) / 1e9
-                        extras["fog_noskip_batch8"] = {"launch_ms": ms, "frames_per_launch": 8, "Mray_steps_per_s": sr * 8 / ms / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
-                        del fr
-                    except Exception as e:
-                        extras["fog_noskip_batch8"] = {"error": str(e)}
+                # the sampling loop with every step fetching its taps, batched like the headline
+                try:
+                    fr = torch.empty((8, H, W, 4), dtype=torch.float16, device="cuda")
+                    ms = time_launches(ctx, lambda: V.render_batch(ctx, p_ns, [blob] * 8, fr.data_ptr(), tile_size=TILE), 10)
+                    sr, ss = extras[f"{name}_noskip"]["s_ref"], extras[f"{name}_noskip"]["s_sampled"]
+                    gb = (ss * cfg["b_step"] + W * H * B_RAY) * 8 / (ms * 1e-3) / 1e9
+                    extras[f"{name}_noskip_batch8"] = {"launch_ms": ms, "frames_per_launch": 8, "Mray_steps_per_s": sr * 8 / ms / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+                    del fr
+                except Exception as e:
+                    extras[f"{name}_noskip_batch8"] = {"error": str(e)}
             V.VolumeTexture.generate_standin(ctx, (cfg["n"],) * 3, layout=layout)
             ctx.sync()
             # the N > 1 driver as a world of one (partition + self-gather + un-tile): the like-for-like baseline of the N > 1 lines

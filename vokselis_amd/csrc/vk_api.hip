@@ -1017,6 +1017,7 @@ static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_
         const bool forced = (flags & VK_RENDER_FORCE_SKIP) != 0;
         const bool skip = !(flags & VK_RENDER_NO_SKIP) && (forced || ctx->empty_fraction >= 0.30);
         if (skip && !forced && ctx->empty_fraction >= 0.70) L.debug_flags &= ~4u;
+        if (skip && ctx->empty_fraction < 0.05) L.debug_flags |= 8u;  // forced on (almost) solid material: long dense stretches from the start
         // SAFE=false (no per-axis clamps, 32-bit offsets, index tables in LDS) only when provably
         // harmless: the cell array is < 4 GiB, the tables fit a modest LDS budget, and the camera is
         // near enough that the accumulated position stays within 0.5/n of the box

@@ -94,7 +94,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
-    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory; bit 2: adaptive probing (skip kernels)
+    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory; bit 2: adaptive probing (skip kernels), bit 3: start with long dense stretches
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
     // batched launch: the grid spans n_frames frames, position-major (slot 0 of every frame, then slot 1, ...), so
     // the heaviest tiles of all frames start first.  frames == nullptr: one frame, described by the fields above.
@@ -918,13 +918,14 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                 // material that cannot be skipped: run the dense loop -- no distance look-up, and on the fast path
                 // software-pipelined -- for a stretch that doubles every time the next window confirms it (64 .. 512
                 // trips), then probe again.  Fog pays ~9 % of its trips at the probing price instead of all of them.
-                uint32_t stretch = 64;
+                const uint32_t stretch0 = (L.debug_flags & 8u) ? 256u : 64u;  // bit 3: the census found (almost) nothing to skip
+                uint32_t stretch = stretch0;
                 for (;;) {
                     cs.skips = 0;
                     bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr);
                     const unsigned long long live = __ballot(alive);
                     if (live == 0ull) break;
-                    if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = 64; continue; }
+                    if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = stretch0; continue; }
                     if constexpr (USE_LUT) alive = march_stream<VOL, COUNT, true>(V, r, cs, cell_lut, stretch);
                     else alive = march<VOL, false, SAFE, COUNT, true>(V, r, stretch, cs, nullptr);
                     if (__ballot(alive) == 0ull) break;
