@@ -195,6 +195,10 @@ def main():
     W, H = cfg["W"], cfg["H"]
     batch = args.batch or {"c2": 32, "c4": 4, "c5": 2}[args.config]
     batch = max(1, min(batch, args.steps))
+    if not args.batch:
+        # K frames in ceil(K / batch) launches of (almost) equal size: a padded last launch would march frames nobody counts
+        n_launch = -(-args.steps // batch)
+        batch = -(-args.steps // n_launch)
 
     import torch
 

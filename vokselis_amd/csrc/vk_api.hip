@@ -84,6 +84,10 @@ struct vk_ctx {
         uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0, root_skip = 0;
     } batch[4];
     uint32_t batch_seq = 0;
+    // the order of the last camera a batch computed one for (a still camera costs no host work from batch to batch)
+    std::vector<unsigned char> batch_key;
+    std::vector<uint32_t> batch_order, batch_pos;
+    uint32_t batch_n_active = 0;
     uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
 
     // present targets (next row N1/N2)
@@ -1266,12 +1270,19 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
     uint32_t *h_pos = h_order + (size_t)n_frames * n_tiles;
     uint32_t max_active = 0;
-    std::vector<uint32_t> order, pos;
-    uint32_t n_active = 0;
+    std::vector<uint32_t> &order = ctx->batch_order, &pos = ctx->batch_pos;
+    uint32_t &n_active = ctx->batch_n_active;
     for (uint32_t f = 0; f < n_frames; f++) {
         const float *c = cams + 36 * f;
-        const bool same = f > 0 && std::memcmp(c, c - 36, 144) == 0;  // a still camera costs one order per batch
-        if (!same) compute_tile_order(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, order, pos, n_active);
+        // the tile order depends on the camera (and the frame / volume shape): recomputed only when that changes
+        std::vector<unsigned char> key(144 + 28);
+        std::memcpy(key.data(), c, 144);
+        const uint32_t kk[7] = {(uint32_t)geo_mode, ts, ctx->width, ctx->height, ctx->nx, ctx->ny, ctx->nz};
+        std::memcpy(key.data() + 144, kk, 28);
+        if (key != ctx->batch_key || order.size() != n_tiles) {
+            compute_tile_order(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, order, pos, n_active);
+            ctx->batch_key.swap(key);
+        }
         std::memcpy(fd[f].eye, c, 16);
         std::memcpy(fd[f].inv_proj, c + 20, 64);
         int32_t cr[4];
