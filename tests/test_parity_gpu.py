@@ -314,6 +314,58 @@ def _orbit_cameras(V, n, aspect):
     return [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), aspect).get_proj_view_matrix() for k in range(n)]
 
 
+def test_c2_full_size_batch_and_eight_way_partition(V, O):
+    """The headline configuration at its own size (256^3 stand-in, 1920x1080, dt 0.5, rgba16f): frames of a batched launch
+    and of an 8-rank partition with the weighted deal (emulated on this GPU, gathered by copies) are bitwise equal to
+    vk_render's frames, whose trip counts are the oracle's."""
+    import torch
+
+    W, H, ts = 1920, 1080, 64
+    cams = [V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix(),
+            V.Camera(1.3, 0.2, 2.1, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()]
+    cams = [cams[0], cams[0], cams[1], cams[0]]
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    try:
+        V.VolumeTexture.generate_standin(ctx, (256,) * 3)
+        pipe = V.RaycastPipeline(dt_scale=0.5)
+        singles = []
+        for c in cams:
+            ctx.set_camera_blob(c)
+            pipe.record(ctx)
+            singles.append(ctx.read_backbuffer().view(np.uint16).copy())
+        ctx.reset_step_counts()
+        V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)  # camera 0 again
+        steps = ctx.read_steps()
+        _, rsteps, _ = O.render(cams[0], O.volume_standin_u8(256), W, H, dt_scale=0.5, tile=(640, 300, 640, 64))
+        assert (steps[300:364, 640:1280] == rsteps[300:364, 640:1280]).all()
+        B = len(cams)
+        frames = torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda")
+        V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=ts)
+        ctx.sync()
+        got = frames.cpu().numpy().view(np.uint16)
+        for j in range(B):
+            assert (got[j] == singles[j]).all(), ("batch", j)
+        nr, k = 8, 2
+        ctx.set_root_skip(k)
+        cap = V.partition_slots(W, H, ts, nr, k)
+        gathered = None
+        for r in range(nr):
+            buf = torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda")
+            bid, act = V.render_batch(ctx, pipe, cams, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
+            if gathered is None:
+                gathered = torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda")
+            ctx.sync()
+            gathered[r] = buf[:act]
+        frames.zero_()
+        V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
+        ctx.sync()
+        got = frames.cpu().numpy().view(np.uint16)
+        for j in range(B):
+            assert (got[j] == singles[j]).all(), ("partition", j)
+    finally:
+        ctx.close()
+
+
 def test_batch_tile_renderer_over_rccl_world1(V, O):
     """The N > 1 driver (vokselis_amd.dist.BatchTileRenderer) as a world of one over the library's own RCCL
     communicator (vk_comm_init_rank / vk_gather_tiles): batches of 4 frames, a new camera every frame, a partial
