@@ -294,6 +294,27 @@ def test_render_batch_equals_single_frames(V, O):
             ctx.set_root_skip(0)
         finally:
             ctx.close()
+    # the compute twin (records layout) and the procedural mode (no volume) through the same batched launch
+    xcams = [V.Camera(3.0 + 0.1 * k, -0.5 + 0.1 * k, 1.0 + 0.4 * k, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix() for k in range(4)]
+    for mode, dt in ((V.MODE_COMPUTE_NEAREST, 1.0), (V.MODE_PROCEDURAL, 3.0)):
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            if mode == V.MODE_COMPUTE_NEAREST:
+                V.VolumeTexture.generate_xor(ctx, (64, 64, 64), 0.0)
+            pipe = V.RaycastPipeline(mode, dt_scale=dt)
+            singles = []
+            for c in xcams:
+                ctx.set_camera_blob(c)
+                pipe.record(ctx)
+                singles.append(ctx.read_backbuffer().copy())
+            frames = torch.zeros((len(xcams), H, W, 4), dtype=torch.float32, device="cuda")
+            V.render_batch(ctx, pipe, xcams, frames.data_ptr(), tile_size=ts)
+            ctx.sync()
+            got = frames.cpu().numpy()
+            for j in range(len(xcams)):
+                assert (got[j].view(np.uint32) == singles[j].view(np.uint32)).all(), (mode, j)
+        finally:
+            ctx.close()
     # error behaviour: counters are per frame, whole frames need one rank, capacity is checked
     ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
     try:
