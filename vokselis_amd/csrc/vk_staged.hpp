@@ -319,7 +319,12 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     for (uint32_t si = 0; si < Es; si++) {
                         const uint32_t sv = (uint32_t)ilS + si;
                         const unsigned char *sbase = base + (((uint64_t)(npf * nbm) * (uint64_t)(sv >> 3)) << 10) + ((sv & 7u) << 7);
-                        __builtin_amdgcn_global_load_lds(sbase + voff, (__attribute__((address_space(3))) void *)(stage_win + (si * slicePieces + j) * 16u), 16, 0, 0);
+                        // global_load_lds_dwordx4 with the slice's base in a scalar pair and the lane's 32-bit offset: no vector
+                        // arithmetic per load (the builtin only takes a 64-bit per-lane address: one v_lshl_add_u64 each)
+                        const uint32_t lds_dst = win_lds + (si * slicePieces + j) * 16u;
+                        uint32_t keep_m0;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep_m0) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
                     }
                 }
             }
