@@ -124,7 +124,8 @@ def main():
     xs = np.array([0.0, 0.001, 0.0031307, 0.0031308, 0.0031309, 0.01, 0.2, 0.5, 0.95, 1.0], np.float32)
     rs = np.array([0.0, 25 / 255, 25.5 / 255, 26 / 255, 0.1, 0.100001, 0.5, 0.9, 0.95, 1.0], np.float32)
     np.savez_compressed(os.path.join(OUT, "units.npz"), box_o=o, box_d=d, box_t0=t0, box_t1=t1, tri_pts=pts, tri_ramp_x=tri,
-                        tri_standin=tri_s, srgb_x=xs, srgb_y=R.linear_to_srgb(xs), alpha_r=rs, alpha_a=R.transfer_alpha(rs))
+                        tri_standin=tri_s, srgb_x=xs, srgb_y=R.linear_to_srgb(xs), alpha_r=rs, alpha_a=R.transfer_alpha(rs),
+                        alpha_raw=(rs * np.float32(255.0)).astype(np.float32), alpha_a_raw=R.transfer_alpha((rs * np.float32(255.0)).astype(np.float32), raw_unorm8=True))
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {OUT}: {tot / 1024:.0f} KiB")
 

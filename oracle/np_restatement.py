@@ -54,7 +54,7 @@ def intersect_box(o, d, lo, hi):
     return t0, t1
 
 
-def sample_trilinear(vol: np.ndarray, p):
+def sample_trilinear(vol: np.ndarray, p, raw=False):
     """Linear, clamp-to-edge sample of a [nz,ny,nx] u8 (R8Unorm) or f16 volume at p in [0,1]^3."""
     nz, ny, nx = vol.shape
     dims = (nx, ny, nz)
@@ -86,15 +86,19 @@ def sample_trilinear(vol: np.ndarray, p):
     c01, c11 = lerp(t[4], t[5], fr[0]), lerp(t[6], t[7], fr[0])
     c0, c1 = lerp(c00, c10, fr[1]), lerp(c01, c11, fr[1])
     r = lerp(c0, c1, fr[2])
-    if is_u8:
+    if is_u8 and not raw:  # raw: the filtered taps stay on their 0..255 scale (the march: transfer_alpha carries the 1/255)
         r = (r * (f32(1.0) / f32(255.0))).astype(np.float32)
     return r, nonempty
 
 
-def transfer_alpha(r):
-    v = np.fmin(f32(0.9), r)  # clamp(0.4, 0.9, v) with low > high == min(0.9, v)  
-    inv = f32(1.0) / (f32(1.2) - f32(0.10))
-    s = ((v - f32(0.10)) * inv).astype(np.float32)
+def transfer_alpha(x, raw_unorm8=False):
+    """min(0.9, v) (clamp with low > high) then smoothstep(0.1, 1.2, .), with the affine part as ONE fused op
+    whose constants carry the sample's scale: x is a value (c = 0.9, k1 = 1/1.1) or filtered R8Unorm taps on their
+    0..255 scale (c = 229.5, k1 = 1/(255*1.1)); k2 = -0.1/1.1 (constants rounded from float64)."""
+    c = f32(229.5) if raw_unorm8 else f32(0.9)
+    k1 = f32(1.0 / (255.0 * 1.1)) if raw_unorm8 else f32(1.0 / 1.1)
+    k2 = f32(-0.1 / 1.1)
+    s = fma(np.fmin(np.asarray(x, np.float32), c), k1, k2)
     s = np.fmin(np.fmax(s, f32(0.0)), f32(1.0))
     return ((s * s).astype(np.float32) * fma(f32(-2.0), s, f32(3.0))).astype(np.float32)
 
@@ -156,8 +160,8 @@ def render_naive(camera_blob: bytes, vol: np.ndarray, W: int, H: int, dt_scale: 
     while active.any():
         idx = np.nonzero(active)[0]
         pa = [p[i][idx] for i in range(3)]
-        r, nonempty = sample_trilinear(vol, pa)
-        a = transfer_alpha(r)
+        r, nonempty = sample_trilinear(vol, pa, raw=True)
+        a = transfer_alpha(r, raw_unorm8=(vol.dtype == np.uint8))
         rgb = vertigo(a)
         nst[idx] += 1
         nsm[idx] += nonempty.astype(np.uint32)

@@ -79,7 +79,7 @@ def lib() -> C.CDLL:
         L.vo_sample_trilinear.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                           C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         L.vo_sample_trilinear.restype = C.c_float
-        L.vo_transfer_alpha.argtypes = [C.c_float]
+        L.vo_transfer_alpha.argtypes = [C.c_float, C.c_int]
         L.vo_transfer_alpha.restype = C.c_float
         L.vo_vertigo.argtypes = [C.c_float, C.POINTER(C.c_float)]
         L.vo_linear_to_srgb.argtypes = [C.c_float]

@@ -267,9 +267,10 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
     float c01 = lerp_fma(t[4], t[5], fx), c11 = lerp_fma(t[6], t[7], fx);
     float c0 = lerp_fma(c00, c10, fy), c1 = lerp_fma(c01, c11, fy);
     float r = lerp_fma(c0, c1, fz);
-    if (format == VO_FMT_R8_UNORM && !(flags & VO_FLAG_TAPNORM_PER_TAP)) {
+    if (format == VO_FMT_R8_UNORM && !(flags & VO_FLAG_TAPNORM_PER_TAP) && !(flags & VO_FLAG_RAW_UNORM8)) {
         /* R8Unorm normalisation applied once after filtering (linear => same value in exact
-         * arithmetic as normalising each tap); 1/255 rounded to f32. */
+         * arithmetic as normalising each tap); 1/255 rounded to f32.  The march itself asks for the raw
+         * (0..255 scale) value, VO_FLAG_RAW_UNORM8: its transfer function carries the 1/255 (vo_transfer_alpha). */
         r = r * (1.0f / 255.0f);
     }
     return r;
@@ -278,13 +279,18 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
 /* ------------------------------------------------------------------------- */
 /* Transfer function + compositing pieces                                     */
 
-float vo_transfer_alpha(float r) {
-    /* raycast_naive.wgsl:106: clamp(vec3(0.4), vec3(.9), val) == min(max(0.4,0.9), val) (F8) */
-    float v = vmin(0.9f, r);
-    /* raycast_naive.wgsl:107: smoothstep(0.10, 1.2, v); the divide by (1.2-0.1) is a multiply by
-     * the f32 reciprocal, as GPU compilers lower it */
-    const float inv = 1.0f / (1.2f - 0.10f);
-    float s = (v - 0.10f) * inv;
+float vo_transfer_alpha(float x, int raw_unorm8) {
+    /* raycast_naive.wgsl:106: clamp(vec3(0.4), vec3(.9), val) == min(max(0.4,0.9), val) (F8)
+     * raycast_naive.wgsl:107: smoothstep(0.10, 1.2, v) = t*t*(3 - 2t), t = clamp((v - 0.1) / 1.1).
+     * Specification (round 2): the affine map of t is ONE fused op, t = clamp(fma(min(x, c), k1, k2)), with the scale
+     * of the sample folded into its constants -- x is either a value (f16 volumes, per-tap-normalised taps: c = 0.9,
+     * k1 = 1/1.1) or the filtered R8Unorm taps on their 0..255 scale (c = 0.9 * 255, k1 = 1/(255 * 1.1)); k2 = -0.1/1.1.
+     * WGSL leaves both the R8Unorm conversion and the lowering of smoothstep's divide to the implementation; this
+     * reading costs the GPU two instructions less per sample than "multiply by 1/255, subtract, multiply". */
+    const float c = raw_unorm8 ? 229.5f : 0.9f;
+    const float k1 = raw_unorm8 ? (float)(1.0 / (255.0 * 1.1)) : (float)(1.0 / 1.1);
+    const float k2 = (float)(-0.1 / 1.1);
+    float s = fmaf(vmin(x, c), k1, k2);
     s = vmin(vmax(s, 0.0f), 1.0f);
     return (s * s) * fmaf(-2.0f, s, 3.0f);
 }
@@ -379,8 +385,9 @@ static void pixel_naive(const vo_render_args *a, uint32_t x, uint32_t y, float o
     uint32_t n = 0, ns = 0;
     for (float t = th[0]; t < th[1]; t = t + dt) { /* :101 */
         int nonempty = 0;
-        float r = vo_sample_trilinear(a->volume, a->nx, a->ny, a->nz, a->format, p, a->flags, &nonempty);
-        float al = vo_transfer_alpha(r);
+        const int raw8 = a->format == VO_FMT_R8_UNORM && !(a->flags & VO_FLAG_TAPNORM_PER_TAP);
+        float r = vo_sample_trilinear(a->volume, a->nx, a->ny, a->nz, a->format, p, a->flags | VO_FLAG_RAW_UNORM8, &nonempty);
+        float al = vo_transfer_alpha(r, raw8);
         float rgb[3];
         vo_vertigo(al, rgb);
         n++;

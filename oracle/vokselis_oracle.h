@@ -55,7 +55,8 @@ enum { VO_MODE_NAIVE_TRILINEAR = 0, VO_MODE_COMPUTE_NEAREST = 1, VO_MODE_PROCEDU
 /* Flags for vo_render. */
 enum {
     VO_FLAG_NO_EARLY_OUT = 1, /* count/march S_nominal: ignore the alpha>=0.95 break */
-    VO_FLAG_TAPNORM_PER_TAP = 2 /* ablation: normalise u8 taps (c/255) before the lerps */
+    VO_FLAG_TAPNORM_PER_TAP = 2, /* ablation: normalise u8 taps (c/255) before the lerps */
+    VO_FLAG_RAW_UNORM8 = 4 /* vo_sample_trilinear: leave filtered R8Unorm taps on their 0..255 scale (the march's own call) */
 };
 
 typedef struct vo_render_args {
@@ -92,7 +93,7 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
                           const float p[3], int flags, int *any_above_25);
 
 /* shaders/raycast_naive.wgsl:106-107 (clamp with low>high read as min(0.9,v)). */
-float vo_transfer_alpha(float r);
+float vo_transfer_alpha(float x, int raw_unorm8);
 /* shaders/raycast_naive.wgsl:70-81. */
 void vo_vertigo(float a, float rgb[3]);
 /* shaders/raycast_naive.wgsl:63-68. */

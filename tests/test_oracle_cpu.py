@@ -127,13 +127,20 @@ def test_units_srgb_and_transfer(O, golden):
         assert abs(O.lib().vo_linear_to_srgb(float(x)) - y) <= 2e-7
     assert O.lib().vo_linear_to_srgb(0.0031308) == pytest.approx(12.92 * 0.0031308, rel=1e-6)  # the knee
     for r, a in zip(u["alpha_r"], u["alpha_a"]):
-        assert O.lib().vo_transfer_alpha(float(r)) == a
+        assert O.lib().vo_transfer_alpha(float(r), 0) == a
+    for x, a in zip(u["alpha_raw"], u["alpha_a_raw"]):  # filtered R8Unorm taps on their 0..255 scale
+        assert O.lib().vo_transfer_alpha(float(x), 1) == a
     # u8 <= 25 is exactly transparent, 26 is not; opacity saturates at min(0.9, r)
-    inv255 = np.float32(1.0) / np.float32(255.0)
-    assert O.lib().vo_transfer_alpha(float(np.float32(25) * inv255)) == 0.0
-    assert O.lib().vo_transfer_alpha(float(np.float32(26) * inv255)) > 0.0
-    amax = O.lib().vo_transfer_alpha(1.0)
-    assert amax == O.lib().vo_transfer_alpha(0.9) and amax == pytest.approx(0.8174, abs=2e-4)
+    assert O.lib().vo_transfer_alpha(25.0, 1) == 0.0 and O.lib().vo_transfer_alpha(25.49, 1) == 0.0
+    assert O.lib().vo_transfer_alpha(26.0, 1) > 0.0
+    assert O.lib().vo_transfer_alpha(0.0999755859375, 0) == 0.0 and O.lib().vo_transfer_alpha(0.1002197265625, 0) > 0.0  # the f16 neighbours of 0.1
+    amax = O.lib().vo_transfer_alpha(1.0, 0)
+    assert amax == O.lib().vo_transfer_alpha(0.9, 0) and amax == pytest.approx(0.8174, abs=2e-4)
+    assert O.lib().vo_transfer_alpha(255.0, 1) == pytest.approx(amax, abs=1e-6) and O.lib().vo_transfer_alpha(255.0, 1) == O.lib().vo_transfer_alpha(229.5, 1)
+    # the two scales are the same function: |alpha(x/255) - alpha_raw(x)| stays at rounding level
+    xs = np.linspace(0, 255, 511, dtype=np.float32)
+    d = [abs(O.lib().vo_transfer_alpha(float(x), 1) - O.lib().vo_transfer_alpha(float(np.float32(x) / np.float32(255.0)), 0)) for x in xs]
+    assert max(d) <= 2e-6
 
 
 def test_tap_normalisation_order_is_immaterial(O, cameras, golden_volumes):

@@ -269,11 +269,16 @@ __device__ __forceinline__ float linear_to_srgb(float x) {
     return 1.055f * p - 0.055f;
 }
 
-// raycast_naive.wgsl:106-107 -- bit-exact with vo_transfer_alpha
-__device__ __forceinline__ float transfer_alpha(float r) {
-    float v = fminf(0.9f, r);
-    const float inv = 1.0f / (1.2f - 0.10f);
-    float s = (v - 0.10f) * inv;
+// raycast_naive.wgsl:106-107 -- bit-exact with vo_transfer_alpha: min(x, c), then smoothstep's affine map as ONE
+// fused op whose constants carry the scale of x, then t*t*(3 - 2t).  SCALE 0: x is a value (f16 volumes); 1: filtered
+// R8Unorm taps on their 0..255 scale; 2: the same times 2^-24 (the staged kernel's u8 taps enter the filter as f16
+// subnormals; a power of two folds into c and k1 exactly).  5 VALU (min, fma+clamp, mul, fma, mul).
+template <int SCALE>
+__device__ __forceinline__ float transfer_alpha(float x) {
+    constexpr float k2 = (float)(-0.1 / 1.1);
+    constexpr float c = SCALE == 0 ? 0.9f : (SCALE == 1 ? 229.5f : 229.5f * 0x1p-24f);
+    constexpr float k1 = SCALE == 0 ? (float)(1.0 / 1.1) : (SCALE == 1 ? (float)(1.0 / (255.0 * 1.1)) : (float)(1.0 / (255.0 * 1.1)) * 16777216.0f);
+    float s = fmaf(fminf(x, c), k1, k2);
     s = fminf(fmaxf(s, 0.0f), 1.0f);
     return (s * s) * fmaf(-2.0f, s, 3.0f);
 }
@@ -617,8 +622,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         }
         float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
         float r = fmaf(fz, c1 - c0, c0);
-        if (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) r = r * (1.0f / 255.0f);
-        const float a = transfer_alpha(r);
+        const float a = transfer_alpha<(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) ? 1 : 0>(r);
         // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
         constexpr double kk = 6.28318 / 6.283185307179586476925;
         constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
@@ -671,8 +675,7 @@ __device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, C
         xlerp_cell<VOL>(cur, fx, c00, c10, c01, c11);
         float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
         float v = fmaf(fz, l1 - l0, l0);
-        if (VOL == VOL_P8 || VOL == VOL_P16) v = v * (1.0f / 255.0f);
-        const float a = transfer_alpha(v);
+        const float a = transfer_alpha<(VOL == VOL_P8 || VOL == VOL_P16) ? 1 : 0>(v);
         constexpr double kk = 6.28318 / 6.283185307179586476925;
         constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
         constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
@@ -754,8 +757,7 @@ __device__ __forceinline__ void march_b9_stream(const VolumeDesc &V, RayState &r
         const float c01 = fmaf(fx, tp[5] - tp[4], tp[4]), c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
         const float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
         float v = fmaf(fz, l1 - l0, l0);
-        if (VOL == VOL_B9U8) v = v * (1.0f / 255.0f);
-        const float a = transfer_alpha(v);
+        const float a = transfer_alpha<VOL == VOL_B9U8 ? 1 : 0>(v);
         constexpr double kk = 6.28318 / 6.283185307179586476925;
         constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
         constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
@@ -828,8 +830,7 @@ __device__ __forceinline__ void march_quads_stream(const VolumeDesc &V, RayState
         const float c01 = fmaf(fx, tp[5] - tp[4], tp[4]), c11 = fmaf(fx, tp[7] - tp[6], tp[6]);
         const float l0 = fmaf(fy, c10 - c00, c00), l1 = fmaf(fy, c11 - c01, c01);
         float v = fmaf(fz, l1 - l0, l0);
-        if (VOL == VOL_Q8) v = v * (1.0f / 255.0f);
-        const float a = transfer_alpha(v);
+        const float a = transfer_alpha<VOL == VOL_Q8 ? 1 : 0>(v);
         constexpr double kk = 6.28318 / 6.283185307179586476925;
         constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
         constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);

@@ -162,8 +162,9 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c) {
 }
 
 // One sample's transfer function, colour and compositing: the statements of march() after the filter.
+template <int SCALE>
 __device__ __forceinline__ void composite_step(float v, float &A, float &Gr, float &Gg, float &Gb) {
-    const float a = transfer_alpha(v);
+    const float a = transfer_alpha<SCALE>(v);
     constexpr double kk = 6.28318 / 6.283185307179586476925;
     constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
     constexpr float pd1 = (float)(0.15 * kk), pd2 = (float)(0.20 * kk);
@@ -192,16 +193,14 @@ __device__ __forceinline__ float filter_pairs(const uint32_t lo[4], const uint32
     // u8 taps take the f16 path too: the byte b, read as an f16 bit pattern, is the subnormal b * 2^-24, which
     // v_fma_mix_f32 converts exactly.  The whole filter is linear, every intermediate stays in f32's normal range, and
     // a power-of-two scale commutes with rounding: each value below is 2^-24 times the specified one, bit for bit, and
-    // the final constant folds the 2^24 back (f32(1/255) * 2^24 is exact).  Eight conversions per sample saved.
+    // the transfer function's constants fold the 2^24 back (exactly).  Eight conversions per sample saved.
     float dl[4], c[4];  // x edges at (dy, dz) = (0,0) (1,0) (0,1) (1,1); the four differences first: no back-to-back dependence
 #pragma unroll
     for (int j = 0; j < 4; j++) dl[j] = mix_sub(tp[2 * j + 1], tp[2 * j]);
 #pragma unroll
     for (int j = 0; j < 4; j++) c[j] = mix_lerp(fx, dl[j], tp[2 * j]);
     const float c0 = fmaf(fy, c[1] - c[0], c[0]), c1 = fmaf(fy, c[3] - c[2], c[2]);
-    float v = fmaf(fz, c1 - c0, c0);
-    if (U8) v = v * ((1.0f / 255.0f) * 16777216.0f);
-    return v;
+    return fmaf(fz, c1 - c0, c0);  // u8: 2^-24 times the filtered taps (transfer_alpha<2> carries the scale)
 }
 
 // One step with the 8 taps read from the brick copy itself (global memory): the always-correct path for what the
@@ -343,7 +342,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     uint32_t lo[4], hi[4];
                     lds_tap_pairs<U8>((uint32_t)a0, (uint32_t)(a0 + rowB), (uint32_t)(a0 + sliceB), (uint32_t)(a0 + sliceB + rowB), lo, hi);
                     const float v = filter_pairs<U8, PERM>(lo, hi, fx, fy, fz);
-                    composite_step(v, A, Gr, Gg, Gb);
+                    composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                     if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
                     p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
                     t = t + dt;
@@ -352,7 +351,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         } else if (live && iS == sig) {
             // ---- even a one-cell slab exceeds the window: the rearmost rays take one step from global memory
             const float v = sample_global<VOL, PERM>(D, p, fn);
-            composite_step(v, A, Gr, Gg, Gb);
+            composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
             if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
             p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
             t = t + dt;
@@ -364,7 +363,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         if (alive && !fit) {
             while (t < t1 && A < 0.95f) {
                 const float v = sample_global<VOL, PERM>(D, p, fn);
-                composite_step(v, A, Gr, Gg, Gb);
+                composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                 if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
                 p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
                 t = t + dt;
