@@ -397,14 +397,14 @@ def main():
                     mk()
                 for mode, p, fl in (("noskip", p_ns, V.RENDER_NO_SKIP), ("skip", p_sk, V.RENDER_FORCE_SKIP)):
                     sr, ss = count_steps(ctx, V, fl)
-                    ms = time_launches(ctx, lambda: p.record(ctx), it)
+                    ms = time_launches(ctx, lambda: p.record(ctx), 100, warm=20)  # steady state: the first launches after a new volume run slower
                     gb = (ss * cfg["b_step"] + W * H * B_RAY) / (ms * 1e-3) / 1e9
                     extras[f"{name}_{mode}"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
                 # the sampling loop with every step fetching its taps, batched like the headline
                 try:
                     fr = torch.empty((8, H, W, 4), dtype=torch.float16, device="cuda")
-                    ms = time_launches(ctx, lambda: V.render_batch(ctx, p_ns, [blob] * 8, fr.data_ptr(), tile_size=TILE), 10)
+                    ms = time_launches(ctx, lambda: V.render_batch(ctx, p_ns, [blob] * 8, fr.data_ptr(), tile_size=TILE), 12, warm=4)
                     sr, ss = extras[f"{name}_noskip"]["s_ref"], extras[f"{name}_noskip"]["s_sampled"]
                     gb = (ss * cfg["b_step"] + W * H * B_RAY) * 8 / (ms * 1e-3) / 1e9
                     extras[f"{name}_noskip_batch8"] = {"launch_ms": ms, "frames_per_launch": 8, "Mray_steps_per_s": sr * 8 / ms / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}

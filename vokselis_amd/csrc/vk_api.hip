@@ -88,6 +88,7 @@ struct vk_ctx {
     std::vector<unsigned char> batch_key;
     std::vector<uint32_t> batch_order, batch_pos;
     uint32_t batch_n_active = 0;
+    uint32_t naive_lds_pad = 0;  // debug: extra dynamic LDS per workgroup of the cell kernels (caps the waves per SIMD)
     uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
 
     // present targets (next row N1/N2)
@@ -740,7 +741,7 @@ static void launch_naive(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V_i
     if (!SKIP && V.lut) V.lut += cell_lut_entries(V.nx, V.ny, V.nz);  // byte-offset copy of the tables
     // the fast path of the cell layouts keeps its per-axis index tables in LDS (vk_kernels.hpp: load_cell_luts)
     constexpr bool lut = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16) && !SAFE;
-    const uint32_t lds = lut ? cell_lut_bytes(V.nx, V.ny, V.nz) : 0u;
+    const uint32_t lds = (lut ? cell_lut_bytes(V.nx, V.ny, V.nz) : 0u) + ctx->naive_lds_pad;  // (pad: occupancy experiments, vk_debug_set_param)
     if (f16) {
         if (count) hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, true>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
         else hipLaunchKernelGGL((raymarch_naive_kernel<VOL, SKIP, SAFE, OUT_RGBA16F, false>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
@@ -1655,6 +1656,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     const std::string n(name);
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
+    else if (n == "naive_lds_pad") ctx->naive_lds_pad = (uint32_t)value;          // experiments: caps the cell kernels' waves per SIMD
     else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)
     else return fail(ctx, VK_ERR_INVALID, "vk_debug_set_param: unknown parameter " + n);
     return VK_OK;
