@@ -5,10 +5,14 @@ import numpy as np
 import vokselis_amd as V
 from vokselis_amd import _native as N
 W, H = 1920, 1080
-flags = V.RENDER_NO_SKIP if (len(sys.argv) > 1 and sys.argv[1] == "noskip") else 0
+flags = V.RENDER_NO_SKIP if ("noskip" in sys.argv[1:]) else 0
 cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
 ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-V.VolumeTexture.generate_standin(ctx, (256,) * 3, layout=V.LAYOUT_PACKED_PAIRS); ctx.update()
+if "fog" in sys.argv[1:]:
+    V.VolumeTexture.generate_fog(ctx, (256,) * 3, layout=V.LAYOUT_PACKED_PAIRS)
+else:
+    V.VolumeTexture.generate_standin(ctx, (256,) * 3, layout=V.LAYOUT_PACKED_PAIRS)
+ctx.update()
 pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=0.5, flags=flags | V.RENDER_COUNT)
 pipe.record(ctx); ctx.sync()
 nb = 30 * 17 * 64
@@ -26,7 +30,8 @@ dur = en - st
 print("blocks traced", ok.sum(), "frame span us", en.max())
 print("duration us percentiles 50/90/99/max:", np.percentile(dur, [50, 90, 99, 100]).round(1))
 print("start us percentiles 50/90/99/max:", np.percentile(st, [50, 90, 99, 100]).round(1))
-edges = np.linspace(0, en.max(), 21)
+print("waves resident per SIMD at start of each block: computed below from placement")
+edges = np.linspace(0, en.max(), 31)
 for a, b in zip(edges[:-1], edges[1:]):
     mid = (a + b) / 2
     print(f"t={mid:7.1f} us  in flight {int(((st <= mid) & (en > mid)).sum()):6d}")

@@ -88,6 +88,7 @@ struct vk_ctx {
     std::vector<unsigned char> batch_key;
     std::vector<uint32_t> batch_order, batch_pos;
     uint32_t batch_n_active = 0;
+    uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements
     uint32_t naive_lds_pad = 0;  // debug: extra dynamic LDS per workgroup of the cell kernels (caps the waves per SIMD)
     uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
 
@@ -1105,7 +1106,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.trace = nullptr;
     L.frames = nullptr;
     L.n_frames = 1;
-    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u);
+    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u) | (ctx->wave_prio >= 2u ? 32u : 0u);
     if (count && ctx->want_trace) {
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);
@@ -1321,7 +1322,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.compact = compact ? 1u : 0u;
     L.dt_scale = dt_scale;
     L.out = out;
-    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = (flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u;
+    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u) | (ctx->wave_prio >= 2u ? 32u : 0u);
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
     L.n_frames = n_frames;
     const int rc = dispatch_march(ctx, mode, L, flags, far_cam);
@@ -1656,6 +1657,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     const std::string n(name);
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
+    else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
     else if (n == "naive_lds_pad") ctx->naive_lds_pad = (uint32_t)value;          // experiments: caps the cell kernels' waves per SIMD
     else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)
     else return fail(ctx, VK_ERR_INVALID, "vk_debug_set_param: unknown parameter " + n);

@@ -94,7 +94,7 @@ struct LaunchDesc {
     void *out;
     uint32_t *steps;               // optional per-pixel iteration counts [H][W]
     unsigned long long *counters;  // optional {S_ref, S_sampled, census...}
-    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory; bit 2: adaptive probing (skip kernels), bit 3: start with long dense stretches
+    uint32_t debug_flags;          // bit 0: per-pixel march-loop trips instead of iterations (COUNT builds); bit 1 (staged): steps served from global memory; bit 2: adaptive probing (skip kernels), bit 3: start with long dense stretches, bit 4: issue priority by ray length
     unsigned long long *trace;     // optional per-block {start, end, where, work} records (COUNT builds)
     // batched launch: the grid spans n_frames frames, position-major (slot 0 of every frame, then slot 1, ...), so
     // the heaviest tiles of all frames start first.  frames == nullptr: one frame, described by the fields above.
@@ -121,6 +121,17 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t b) {
 // (Dealing the tiles out SIMD by SIMD -- every SIMD one block from each of 8 tiles -- left the per-SIMD work
 // spread at max/mean 1.66: the spread is block-to-block variation inside tiles, not tile placement.
 // tools/experiments/simd_interleaved_block_order.patch)
+
+// Issue priority by the length of the wave's longest ray, in quarters of the longest possible march (n / dt_scale
+// trips): a frame is one or two rounds of resident waves, and under even sharing of a SIMD's issue slots the longest
+// waves -- started first, finished last -- set the frame time while the short ones leave early.  Speed only.
+__device__ __forceinline__ void set_wave_priority(bool hit, float t0, float t1, float dt, float full) {
+    const float trips = hit ? (t1 - t0) / dt : 0.0f;
+    if (__ballot(trips > 0.75f * full)) __builtin_amdgcn_s_setprio(3);
+    else if (__ballot(trips > 0.5f * full)) __builtin_amdgcn_s_setprio(2);
+    else if (__ballot(trips > 0.25f * full)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 
 // ---- dealing positions of the heaviest-first order to ranks ------------------------------------
 // Round j gives one position to every rank, in rank order.  With root_skip = k >= 2 the root (rank 0) sits out every
@@ -911,6 +922,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.px = px; r.py = py; r.pz = pz; r.sx = sx; r.sy = sy; r.sz = sz;
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
+        if (L.debug_flags & 16u) set_wave_priority(true, t0, t1, dt, fmaxf(fnx, fmaxf(fny, fnz)) / L.dt_scale);
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
         else if constexpr (SKIP) {
             if (L.debug_flags & 4u) {

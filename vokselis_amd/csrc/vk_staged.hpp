@@ -247,7 +247,7 @@ __device__ __forceinline__ float sample_global(const StagedDesc &D, const float 
 //    bounds the box) are marched from global memory after the others -- adjacent pixels do not produce such rays
 //    at any sane field of view; the path exists for safety.
 template <int VOL, int PERM, bool COUNT>
-__device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane) {
+__device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane, const float prio_full) {
     constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
     constexpr bool U8 = (VOL == VOL_S8U8);
     constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
@@ -272,6 +272,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     for (;;) {
         const bool live = fit && (t < t1 && A < 0.95f);
         if (__ballot(live) == 0ull) break;  // wave-uniform
+        if (prio_full > 0.0f) set_wave_priority(live, t, t1, dt, prio_full);  // by what is left of the longest ray
         const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
         const int iS = cvt_floor_i32(uS);
         // the slab starts at the rearmost live ray
@@ -427,11 +428,14 @@ __global__ __launch_bounds__(64) void raymarch_staged_kernel(const LaunchDesc L,
     const int c0 = __popcll(__ballot(hit && mj == 0)), c1 = __popcll(__ballot(hit && mj == 1)), c2 = __popcll(__ballot(hit && mj == 2));
     Census cs;
     if (c0 + c1 + c2 != 0) {  // wave-uniform
+        const float full = fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale;
+        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, full);
+        const float prio_full = (L.debug_flags & 32u) ? full : 0.0f;  // re-evaluated in every round
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
-        if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane);
-        else if (copy == 1u) march_staged_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane);
-        else march_staged_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane);
+        if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane, prio_full);
+        else if (copy == 1u) march_staged_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane, prio_full);
+        else march_staged_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane, prio_full);
     }
     if (!pm.valid) return;
     float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
