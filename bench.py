@@ -178,7 +178,16 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         dims = (V.native.C.c_uint32 * 3)()
         lay, nbytes = V.native.C.c_int(), V.native.C.c_size_t()
         V.native.check(ctx.handle, V.native.lib().vk_volume_info(ctx.handle, dims, None, V.native.C.byref(lay), V.native.C.byref(nbytes)))
-        return {"workload": cfg["name"], "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
+        # the config's "dense-core variant" (SURVEY 8d): the same fog with a dense ball at the centre -- rays through the
+        # middle of the image leave by the opacity early-out, so S_ref < S_nominal and waves run partly empty
+        fmt = V.FMT_R8_UNORM if cfg["fmt"] == "u8" else V.FMT_R16_FLOAT
+        V.VolumeTexture.generate_fog(ctx, (cfg["n"],) * 3, fmt=fmt, seed=cfg["seed"], layout=V.LAYOUT_AUTO, dense_core=True)
+        c_ref, c_samp = count_steps(ctx, V, 0)
+        ms_c = time_launches(ctx, lambda: p.record(ctx), frames, warm=2)
+        alg_c = c_samp * cfg["b_step"] + W * H * B_RAY
+        core = {"launch_ms": ms_c, "s_ref": c_ref, "s_sampled": c_samp, "Mray_steps_per_s": c_ref / ms_c / 1e3,
+                "frac": alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return {"dense_core": core, "workload": cfg["name"], "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
                 "algorithmic_bytes_per_launch": alg, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS, "volume_setup_s": setup,
                 "batch": {"frames_per_launch": nb, "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),

@@ -108,8 +108,11 @@ int vk_volume_upload_device(vk_ctx *ctx, const void *dev, const void *dev2, uint
  * to the oracle's vo_volume_* and to vokselis_amd/volumes.py).  The reference embeds its volume
  * with include_bytes! (volume_texture.rs:33) and that file is absent from the checkout, so the
  * bench and the tests use these.  FOG: u8 in [lo, lo+span) / f16 bit patterns 0x2D1F + h % 656.
- * BONSAI_STANDIN: pot / trunk / canopy / speckled air, u8. */
-enum vk_generator { VK_GEN_FOG = 0, VK_GEN_BONSAI_STANDIN = 1 };
+ * BONSAI_STANDIN: pot / trunk / canopy / speckled air, u8.
+ * FOG_DENSE_CORE: the fog with a dense ball at the centre (radius: a quarter of the smallest dimension; u8 232 + h % 24,
+ * f16 0x3B9A + h % 64), the "dense-core variant" of C4 / C5: rays that reach it leave the loop by the
+ * reference's opacity early-out (raycast_naive.wgsl:115-117). */
+enum vk_generator { VK_GEN_FOG = 0, VK_GEN_BONSAI_STANDIN = 1, VK_GEN_FOG_DENSE_CORE = 2 };
 int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t nz, int format, uint32_t seed,
                        uint32_t lo, uint32_t span, int layout);
 /* XorCompute (examples/xor/xor_compute.rs:93-200): one dispatch of shaders/xor.wgsl `cs_main` at

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         L.vo_volume_standin_u8.argtypes = [C.c_uint32] * 4 + [C.c_void_p]
         L.vo_volume_fog_u8.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
         L.vo_volume_fog_f16.argtypes = [C.c_uint32] * 4 + [C.c_void_p]
+        L.vo_volume_fog_core_u8.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_void_p]
+        L.vo_volume_fog_core_f16.argtypes = [C.c_uint32] * 4 + [C.c_int, C.c_void_p]
         L.vo_dispatch_optimal.argtypes = [C.c_uint32, C.c_uint32]
         L.vo_dispatch_optimal.restype = C.c_uint32
         L.vo_image_dimentions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -206,17 +208,17 @@ def volume_standin_u8(n, seed=0x5EED0001) -> np.ndarray:
     return out
 
 
-def volume_fog_u8(n, seed=0x5EED0002, lo=20, span=12) -> np.ndarray:
+def volume_fog_u8(n, seed=0x5EED0002, lo=20, span=12, dense_core=False) -> np.ndarray:
     nx, ny, nz = (n, n, n) if np.isscalar(n) else n
     out = np.empty((nz, ny, nx), np.uint8)
-    lib().vo_volume_fog_u8(nx, ny, nz, seed, lo, span, out.ctypes.data)
+    lib().vo_volume_fog_core_u8(nx, ny, nz, seed, lo, span, 1 if dense_core else 0, out.ctypes.data)
     return out
 
 
-def volume_fog_f16(n, seed=0x5EED0004) -> np.ndarray:
+def volume_fog_f16(n, seed=0x5EED0004, dense_core=False) -> np.ndarray:
     nx, ny, nz = (n, n, n) if np.isscalar(n) else n
     out = np.empty((nz, ny, nx), np.uint16)
-    lib().vo_volume_fog_f16(nx, ny, nz, seed, out.ctypes.data)
+    lib().vo_volume_fog_core_f16(nx, ny, nz, seed, 1 if dense_core else 0, out.ctypes.data)
     return out.view(np.float16)
 
 

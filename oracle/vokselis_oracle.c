@@ -818,28 +818,50 @@ void vo_volume_standin_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, 
                     standin_voxel(x, y, (uint32_t)z, nx, ny, nz, seed);
 }
 
-void vo_volume_fog_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint32_t lo, uint32_t span,
-                      uint8_t *out) {
+/* Dense ball at the centre of the fog volumes ("dense-core variant" of C4 / C5): radius a quarter of the
+ * smallest dimension, tested in doubled integer coordinates. */
+static int in_dense_core(uint32_t x, uint32_t y, uint32_t z, uint32_t nx, uint32_t ny, uint32_t nz) {
+    int64_t dx = 2 * (int64_t)x + 1 - (int64_t)nx, dy = 2 * (int64_t)y + 1 - (int64_t)ny, dz = 2 * (int64_t)z + 1 - (int64_t)nz;
+    int64_t m = nx < ny ? (nx < nz ? nx : nz) : (ny < nz ? ny : nz);
+    int64_t r = m / 2;
+    return dx * dx + dy * dy + dz * dz < r * r;
+}
+
+void vo_volume_fog_core_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint32_t lo, uint32_t span, int core,
+                           uint8_t *out) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
     for (int64_t z = 0; z < (int64_t)nz; z++)
         for (uint32_t y = 0; y < ny; y++)
-            for (uint32_t x = 0; x < nx; x++)
-                out[(size_t)x + (size_t)nx * (y + (size_t)ny * (size_t)z)] =
-                    (uint8_t)(lo + (hash3(x, y, (uint32_t)z, seed) >> 8) % span);
+            for (uint32_t x = 0; x < nx; x++) {
+                uint32_t h = hash3(x, y, (uint32_t)z, seed) >> 8;
+                int dense = core && in_dense_core(x, y, (uint32_t)z, nx, ny, nz);
+                out[(size_t)x + (size_t)nx * (y + (size_t)ny * (size_t)z)] = (uint8_t)(dense ? 232u + h % 24u : lo + h % span);
+            }
+}
+
+void vo_volume_fog_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint32_t lo, uint32_t span,
+                      uint8_t *out) {
+    vo_volume_fog_core_u8(nx, ny, nz, seed, lo, span, 0, out);
+}
+
+void vo_volume_fog_core_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, int core, uint16_t *out) {
+    /* f16 bit patterns 0x2D1F (0.08) .. 0x2FAE (0.12): monotone in value, integer-only; core 0x3B9A (0.95) .. 0x3BD9 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t z = 0; z < (int64_t)nz; z++)
+        for (uint32_t y = 0; y < ny; y++)
+            for (uint32_t x = 0; x < nx; x++) {
+                uint32_t h = hash3(x, y, (uint32_t)z, seed) >> 8;
+                int dense = core && in_dense_core(x, y, (uint32_t)z, nx, ny, nz);
+                out[(size_t)x + (size_t)nx * (y + (size_t)ny * (size_t)z)] = (uint16_t)(dense ? 0x3B9Au + h % 64u : 0x2D1Fu + h % 656u);
+            }
 }
 
 void vo_volume_fog_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint16_t *out) {
-    /* f16 bit patterns 0x2D1F (0.08) .. 0x2FAE (0.12): monotone in value, integer-only */
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static)
-#endif
-    for (int64_t z = 0; z < (int64_t)nz; z++)
-        for (uint32_t y = 0; y < ny; y++)
-            for (uint32_t x = 0; x < nx; x++)
-                out[(size_t)x + (size_t)nx * (y + (size_t)ny * (size_t)z)] =
-                    (uint16_t)(0x2D1Fu + (hash3(x, y, (uint32_t)z, seed) >> 8) % 656u);
+    vo_volume_fog_core_f16(nx, ny, nz, seed, 0, out);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -119,6 +119,10 @@ void vo_volume_standin_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, 
 void vo_volume_fog_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint32_t lo,
                       uint32_t span, uint8_t *out);
 void vo_volume_fog_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint16_t *out);
+/* The same fogs with a dense ball at the centre when core != 0 ("dense-core variant" of C4 / C5). */
+void vo_volume_fog_core_u8(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint32_t lo, uint32_t span, int core,
+                           uint8_t *out);
+void vo_volume_fog_core_f16(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, int core, uint16_t *out);
 
 /* xor example's volume generator (next row N3): shaders/xor.wgsl:18-78 `cs_main` at un.time = t
  * (the reference runs it once with time = 0).  Writes nx*ny*nz rgba16f texels (4 x u16)

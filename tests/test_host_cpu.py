@@ -146,6 +146,14 @@ def test_host_volume_generators_match_oracle(O):
         assert (volumes.bonsai_standin(dims, seed=9) == O.volume_standin_u8(dims, seed=9)).all()
         assert (volumes.fog_u8(dims, seed=9) == O.volume_fog_u8(dims, seed=9)).all()
         assert (volumes.fog_f16(dims, seed=9).view(np.uint16) == O.volume_fog_f16(dims, seed=9).view(np.uint16)).all()
+        core8, core16 = O.volume_fog_u8(dims, seed=9, dense_core=True), O.volume_fog_f16(dims, seed=9, dense_core=True)
+        assert (volumes.fog_u8(dims, seed=9, dense_core=True) == core8).all()
+        assert (volumes.fog_f16(dims, seed=9, dense_core=True).view(np.uint16) == core16.view(np.uint16)).all()
+        # the dense-core variants: a ball of radius min(dims)/4 at the centre, fog outside
+        m = min(dims) if not np.isscalar(dims) else dims
+        share = (core8 >= 232).mean()
+        assert abs(share - (4.0 / 3.0) * np.pi * (m / 4.0) ** 3 / core8.size) < 0.02 and (core8[core8 < 232] <= 31).all()
+        assert core16.min() >= np.float16(0.08) and (core16[core8 >= 232] >= np.float16(0.95)).all() and (core16[core8 < 232] <= np.float16(0.12)).all()
     v = O.volume_standin_u8(128)
     assert 0.65 <= (v <= 25).mean() <= 0.9 and v.max() >= 232  # >= 65 % exactly transparent
 

@@ -662,6 +662,20 @@ def test_device_fog_generator_is_bit_identical(V, O):
             assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL and (ctx.read_steps() == rsteps).all()
         finally:
             ctx.close()
+    # the dense-core variants: device generator == oracle generator, through the cells and the staged bricks
+    for fmt, host in ((V.FMT_R8_UNORM, O.volume_fog_u8((48, 40, 56), seed=7, dense_core=True)),
+                      (V.FMT_R16_FLOAT, O.volume_fog_f16((48, 40, 56), seed=7, dense_core=True))):
+        ref, rsteps, _ = O.render(cam, host, 80, 80, dt_scale=0.5)
+        assert rsteps.max() > 2 * rsteps[40, 40] > 0  # the centre ray ends in the core
+        for lay in (V.LAYOUT_AUTO, V.LAYOUT_STAGED):
+            ctx = V.Context(80, 80, backbuffer=(80, 80), out_format=V.OUT_RGBA32F)
+            try:
+                V.VolumeTexture.generate_fog(ctx, (48, 40, 56), fmt=fmt, seed=7, layout=lay, dense_core=True)
+                ctx.set_camera_blob(cam)
+                V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)
+                assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL and (ctx.read_steps() == rsteps).all()
+            finally:
+                ctx.close()
     # the bonsai stand-in made on the device renders bit-identically to the host-uploaded one
     host = O.volume_standin_u8((72, 40, 56), seed=3)
     a, sa, _ = gpu_render(V, cam, host, 80, 80, dt=0.5)
@@ -1080,6 +1094,45 @@ def test_baseline_configs_full_size(V, O, name, n, f16, W, H, seed, tile):
     ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
     assert (steps["auto"][ys, xs] == rsteps[ys, xs]).all()
     assert rsteps[ys, xs].min() > 100  # the tile lies inside the cube's silhouette
+    assert np.abs(imgs["auto"][ys, xs] - ref[ys, xs]).max() <= TOL
+
+
+@pytest.mark.parametrize("name,n,f16,W,H,seed,tile", [
+    ("C4-core", 1024, True, 1920, 1080, 0x5EED0004, (1056, 508, 64, 64)),
+    ("C5-core", 2048, False, 3840, 2160, 0x5EED0005, (2160, 1048, 64, 64)),
+])
+def test_baseline_configs_dense_core_full_size(V, O, name, n, f16, W, H, seed, tile):
+    """The "dense-core variant" of C4 / C5 at full size: the fog with a dense ball at the centre, so that the
+    rays through the middle of the image leave the loop by the opacity early-out while their neighbours march on.  The
+    staged bricks (AUTO) and the dense linear layout give bitwise-identical frames and trip counts (default and forced
+    skipping are the same kernel here); a 64x64 tile across the ball's silhouette matches the CPU oracle."""
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
+    fmt = V.FMT_R16_FLOAT if f16 else V.FMT_R8_UNORM
+    imgs, steps, totals = {}, {}, {}
+    for lname, lay in (("auto", V.LAYOUT_AUTO), ("lin", V.LAYOUT_LINEAR)):
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture.generate_fog(ctx, (n, n, n), fmt=fmt, seed=seed, layout=lay, dense_core=True)
+            ctx.set_camera_blob(cam)
+            ctx.reset_step_counts()
+            V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)
+            imgs[lname], steps[lname] = ctx.read_backbuffer(), ctx.read_steps()
+            totals[lname] = ctx.step_counts()
+            if lname == "auto":  # the production (uninstrumented) kernel gives the same frame
+                V.RaycastPipeline(dt_scale=0.5).record(ctx)
+                assert (ctx.read_backbuffer().view(np.uint32) == imgs["auto"].view(np.uint32)).all()
+        finally:
+            ctx.close()
+    assert (imgs["auto"].view(np.uint32) == imgs["lin"].view(np.uint32)).all(), name
+    assert (steps["auto"] == steps["lin"]).all() and totals["auto"] == totals["lin"], name
+    assert totals["auto"][0] == int(steps["auto"].astype(np.int64).sum())
+    centre = int(steps["auto"][H // 2, W // 2])
+    assert 0 < centre < n and steps["auto"].max() == 2 * n + 1  # the centre ray stops in the ball; rays beside it cross the cube
+    host = O.volume_fog_f16(n, seed=seed, dense_core=True) if f16 else O.volume_fog_u8(n, seed=seed, dense_core=True)
+    ref, rsteps, _ = O.render(cam, host, W, H, dt_scale=0.5, tile=tile)
+    ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
+    assert (steps["auto"][ys, xs] == rsteps[ys, xs]).all()
+    assert rsteps[ys, xs].min() > 100 and 2 * rsteps[ys, xs].min() < rsteps[ys, xs].max()  # the tile straddles the silhouette
     assert np.abs(imgs["auto"][ys, xs] - ref[ys, xs]).max() <= TOL
 
 

@@ -18,7 +18,7 @@ LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, 
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS = 32, 64
-GEN_FOG, GEN_BONSAI_STANDIN = 0, 1
+GEN_FOG, GEN_BONSAI_STANDIN, GEN_FOG_DENSE_CORE = 0, 1, 2
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
 _u32, _i32, _f32, _vp, _sz = C.c_uint32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t

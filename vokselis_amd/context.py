@@ -312,8 +312,9 @@ class VolumeTexture:
 
     @classmethod
     def generate_fog(cls, ctx: Context, dims, fmt=N.FMT_R8_UNORM, seed=0x5EED0002, lo=20, span=12,
-                     layout: int = N.LAYOUT_AUTO) -> "VolumeTexture":
-        return cls.generate(ctx, N.GEN_FOG, dims, fmt, seed, lo, span, layout)
+                     layout: int = N.LAYOUT_AUTO, dense_core: bool = False) -> "VolumeTexture":
+        """Fog (C2-fog, C4, C5); dense_core: with the dense ball at the centre (the configs' early-out variant)."""
+        return cls.generate(ctx, N.GEN_FOG_DENSE_CORE if dense_core else N.GEN_FOG, dims, fmt, seed, lo, span, layout)
 
     @classmethod
     def generate_xor(cls, ctx: Context, dims=(256, 256, 256), time: float = 0.0) -> "VolumeTexture":

@@ -614,7 +614,9 @@ int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t
     int dummy = 0;
     int rc = check_volume_args(ctx, &dummy, nullptr, nx, ny, nz, format, layout);
     if (rc) return rc;
-    if (kind != VK_GEN_FOG && kind != VK_GEN_BONSAI_STANDIN) return fail(ctx, VK_ERR_INVALID, "unknown generator kind");
+    if (kind != VK_GEN_FOG && kind != VK_GEN_BONSAI_STANDIN && kind != VK_GEN_FOG_DENSE_CORE) return fail(ctx, VK_ERR_INVALID, "unknown generator kind");
+    const uint32_t core = kind == VK_GEN_FOG_DENSE_CORE ? 1u : 0u;
+    if (core) kind = VK_GEN_FOG;
     if (format == VK_FMT_RGBA16F_PAIR) return fail(ctx, VK_ERR_UNSUPPORTED, "generators make scalar volumes");
     if (kind == VK_GEN_BONSAI_STANDIN && format != VK_FMT_R8_UNORM) return fail(ctx, VK_ERR_UNSUPPORTED, "the bonsai stand-in is a u8 volume");
     if (kind == VK_GEN_FOG && format == VK_FMT_R8_UNORM && (span == 0 || lo + span > 256)) return fail(ctx, VK_ERR_INVALID, "fog range outside u8");
@@ -626,11 +628,11 @@ int vk_volume_generate(vk_ctx *ctx, int kind, uint32_t nx, uint32_t ny, uint32_t
     // grid-stride kernels: a launch may not exceed 2^32 threads
     const uint64_t blocks = std::min<uint64_t>((n_vox + 255) / 256, 1ull << 22);
     if (kind == VK_GEN_BONSAI_STANDIN)
-        hipLaunchKernelGGL(generate_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+        hipLaunchKernelGGL(generate_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span, core);
     else if (format == VK_FMT_R16_FLOAT)
-        hipLaunchKernelGGL(generate_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+        hipLaunchKernelGGL(generate_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span, core);
     else
-        hipLaunchKernelGGL(generate_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span);
+        hipLaunchKernelGGL(generate_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d, nx, ny, nz, seed, lo, span, core);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, VK_ERR_HIP, std::string("generator launch: ") + hipGetErrorString(e)); }
     return build_from_dense(ctx, d, nullptr, true, nx, ny, nz, format, layout);

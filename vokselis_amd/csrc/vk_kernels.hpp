@@ -1419,10 +1419,19 @@ __device__ __forceinline__ uint32_t standin_voxel(uint32_t x, uint32_t y, uint32
     return (h >> 16) % 21;
 }
 
-// kind 0: fog u8 in [lo, lo+span); 1: fog f16 bit patterns 0x2D1F + h % 656; 2: bonsai stand-in u8
+// kind 0: fog u8 in [lo, lo+span); 1: fog f16 bit patterns 0x2D1F + h % 656; 2: bonsai stand-in u8.
+// core: the fog with a dense ball at the centre (SURVEY 8d, C4 / C5 "dense-core variant"): a voxel is in the core iff
+// (2x+1-nx)^2 + (2y+1-ny)^2 + (2z+1-nz)^2 < (min(nx,ny,nz)/2)^2 (radius: a quarter of the smallest dimension); there
+// u8 = 232 + h % 24 (alpha per step >= 0.8: a ray that enters leaves the loop within two steps), f16 = 0x3B9A + h % 64
+// (0.95 .. 0.98).  Integer arithmetic only.
+__host__ __device__ __forceinline__ bool in_dense_core(uint32_t x, uint32_t y, uint32_t z, uint32_t nx, uint32_t ny, uint32_t nz) {
+    const int64_t dx = 2 * (int64_t)x + 1 - (int64_t)nx, dy = 2 * (int64_t)y + 1 - (int64_t)ny, dz = 2 * (int64_t)z + 1 - (int64_t)nz;
+    const int64_t r = (int64_t)(nx < ny ? (nx < nz ? nx : nz) : (ny < nz ? ny : nz)) / 2;
+    return dx * dx + dy * dy + dz * dz < r * r;
+}
 template <int KIND>
 __global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
-                                                       uint32_t seed, uint32_t lo, uint32_t span) {
+                                                       uint32_t seed, uint32_t lo, uint32_t span, uint32_t core) {
     const uint64_t n = (uint64_t)nx * ny * nz, stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += stride) {  // grid-stride: n may exceed 2^32
         uint32_t x = (uint32_t)(id % nx);
@@ -1432,8 +1441,9 @@ __global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, u
             reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)standin_voxel(x, y, z, nx, ny, nz, seed);
         } else {
             uint32_t h = hash3(x, y, z, seed) >> 8;
-            if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(0x2D1Fu + h % 656u);
-            else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(lo + h % span);
+            const bool dense = core && in_dense_core(x, y, z, nx, ny, nz);
+            if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(dense ? 0x3B9Au + h % 64u : 0x2D1Fu + h % 656u);
+            else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(dense ? 232u + h % 24u : lo + h % span);
         }
     }
 }

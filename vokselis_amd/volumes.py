@@ -75,15 +75,30 @@ def bonsai_standin(n=256, seed=0x5EED0001) -> np.ndarray:
     return out
 
 
-def fog_u8(n=256, seed=0x5EED0002, lo=20, span=12) -> np.ndarray:
-    """Uniform u8 in [lo, lo+span): alpha per step <= 1.4e-3, no ray ever reaches 0.95 (C2-fog)."""
-    nx, ny, nz = _dims(n)
-    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    return (lo + (_hash3(x, y, z, seed) >> np.uint32(8)) % np.uint32(span)).astype(np.uint8)
+def _dense_core(x, y, z, nx, ny, nz):
+    """The dense ball of the "dense-core" fog variants: radius a quarter of the smallest dimension."""
+    dx, dy, dz = 2 * x.astype(np.int64) + 1 - nx, 2 * y.astype(np.int64) + 1 - ny, 2 * z.astype(np.int64) + 1 - nz
+    r = min(nx, ny, nz) // 2
+    return dx * dx + dy * dy + dz * dz < r * r
 
 
-def fog_f16(n=256, seed=0x5EED0004) -> np.ndarray:
-    """f16 bit patterns 0x2D1F (0.08) .. 0x2FAE (0.12) (C4)."""
+def fog_u8(n=256, seed=0x5EED0002, lo=20, span=12, dense_core=False) -> np.ndarray:
+    """Uniform u8 in [lo, lo+span): alpha per step <= 1.4e-3, no ray ever reaches 0.95 (C2-fog); dense_core: 232..255 inside the ball."""
     nx, ny, nz = _dims(n)
     z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    return (np.uint32(0x2D1F) + (_hash3(x, y, z, seed) >> np.uint32(8)) % np.uint32(656)).astype(np.uint16).view(np.float16)
+    h = _hash3(x, y, z, seed) >> np.uint32(8)
+    v = lo + h % np.uint32(span)
+    if dense_core:
+        v = np.where(_dense_core(x, y, z, nx, ny, nz), np.uint32(232) + h % np.uint32(24), v)
+    return v.astype(np.uint8)
+
+
+def fog_f16(n=256, seed=0x5EED0004, dense_core=False) -> np.ndarray:
+    """f16 bit patterns 0x2D1F (0.08) .. 0x2FAE (0.12) (C4); dense_core: 0x3B9A (0.95) .. inside the ball."""
+    nx, ny, nz = _dims(n)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    h = _hash3(x, y, z, seed) >> np.uint32(8)
+    v = np.uint32(0x2D1F) + h % np.uint32(656)
+    if dense_core:
+        v = np.where(_dense_core(x, y, z, nx, ny, nz), np.uint32(0x3B9A) + h % np.uint32(64), v)
+    return v.astype(np.uint16).view(np.float16)
