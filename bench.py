@@ -135,7 +135,16 @@ def cpu_baseline(blob):
     t0 = time.perf_counter()
     _, st1, _ = O.render(blob, vol, W, H, dt_scale=DT_SCALE, threads=1, tile=(0, H // 2 - 32, W, 64))
     t_one = time.perf_counter() - t0
+    # C1 (512x512, dt_scale 1), the reference's own CPU-runnable case, on the same threads (C1 and C2)
+    blob1 = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
+    t1s, s1 = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, steps1, _ = O.render(blob1, vol, 512, 512, dt_scale=1.0, threads=threads)
+        t1s.append(time.perf_counter() - t0)
+        s1 = int(steps1.sum())
     return {
+        "c1_value": s1 / float(np.median(t1s)) / 1e6, "c1_sample": "3 full C1 frames (512x512, dt_scale 1; median), same threads", "c1_s_ref": s1,
         "value": s_ref / t_all / 1e6, "unit": "Mray-steps/s", "cores": threads, "kind": "port",
         "sample": f"3 full C2 frames (median), OpenMP dynamic over rows, {threads} threads; oracle/vokselis_oracle.c",
         "one_thread_value": int(st1.sum()) / t_one / 1e6, "one_thread_sample": "rows 508..571 of the C2 frame, 1 thread",
