@@ -285,7 +285,26 @@ def main():
                     launch_ev.append((a, b))
                 pending[0] = 0
         else:
-            btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport="rccl")
+            # tiles move through the library's own RCCL communicator; should that fail to come up on every rank (librccl
+            # not loadable, communicator refused) the same buffers go through torch.distributed's -- RCCL as well
+            transport, why = os.environ.get("VK_BENCH_TRANSPORT", "rccl"), None
+            try:
+                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                btr, ok, why = None, 0, repr(e)
+            if world > 1:
+                okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                ok = int(okt.item())
+            if not ok:
+                if btr is not None:
+                    btr.close()
+                if transport == "torch":
+                    raise RuntimeError("tile gather could not be set up: %s" % why)
+                print("[bench] library communicator unavailable (%s): gathering through torch.distributed" % why, file=sys.stderr)
+                transport = "torch"
+                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport)
 
             def submit(timed):
                 btr.submit(blob)
@@ -350,8 +369,9 @@ def main():
                     "skip": not args.no_skip,
                     "frames_per_launch": batch,
                     "partition": "one launch per batch of whole frames" if not use_dist else
-                                 f"{TILE}x{TILE} tiles dealt heaviest-first over {world} ranks, one launch + one RCCL gather (library communicator, second stream) + one un-tile per batch of {batch} frames",
+                                 f"{TILE}x{TILE} tiles dealt heaviest-first over {world} ranks, one launch + one RCCL gather (second stream) + one un-tile per batch of {batch} frames",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
+                    **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
                 "repeats": repeats, "repeat_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
                 "device": info["device_name"], "volume_setup_s": t_volume,
