@@ -432,6 +432,30 @@ def main():
                                                  "Mray_steps_per_s": s_ref / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
             except Exception as e:
                 extras["single_frame_launch"] = {"error": str(e)}
+            try:
+                # the frame stream of an orbiting camera (src/camera.rs rotates on input): every frame of every batch its own
+                # camera, so the per-camera host work (tile order, cull rectangle, descriptors) is inside the wall time
+                nb, B = 8, 32
+                orbit = [[V.Camera(1.0, 0.5 + 0.1 * ((i * B + j) % 7) / 7.0, 1.0 + 6.28318 * (i * B + j) / (nb * B), (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()
+                          for j in range(B)] for i in range(nb)]
+                ofr = torch.empty((B, H, W, 4), dtype=torch.float16, device="cuda")
+                V.render_batch(ctx, pipe, orbit[0], ofr.data_ptr(), tile_size=TILE)
+                ctx.sync()
+                h0 = time.perf_counter()
+                for cams in orbit[:3]:
+                    V.render_batch(ctx, pipe, cams, ofr.data_ptr(), tile_size=TILE)
+                host_us = (time.perf_counter() - h0) / (3 * B) * 1e6
+                ctx.sync()
+                t0 = time.perf_counter()
+                for cams in orbit:
+                    V.render_batch(ctx, pipe, cams, ofr.data_ptr(), tile_size=TILE)
+                ctx.sync()
+                msf = (time.perf_counter() - t0) / (nb * B) * 1e3
+                del ofr
+                extras["orbit_one_camera_per_frame"] = {"ms_per_frame": msf, "frames": nb * B, "frames_per_launch": B, "host_us_per_camera": host_us,
+                                                        "note": "wall time of 8 batches of 32 distinct cameras (one orbit); the views differ, so the march work per frame does too"}
+            except Exception as e:
+                extras["orbit_one_camera_per_frame"] = {"error": str(e)}
             it = 50
             p_ns = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_NO_SKIP)
             p_sk = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_FORCE_SKIP)

@@ -88,6 +88,8 @@ struct vk_ctx {
     std::vector<unsigned char> batch_key;
     std::vector<uint32_t> batch_order, batch_pos;
     uint32_t batch_n_active = 0;
+    uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
+    uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames
     uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements
     uint32_t naive_lds_pad = 0;  // debug: extra dynamic LDS per workgroup of the cell kernels (caps the waves per SIMD)
     uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
@@ -810,77 +812,78 @@ static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) { cull_rect_cam
 // round-robining them over ranks) shortens it.  The cost estimate is the nominal step count of a
 // 3x3 grid of rays per tile, from the same camera maths as the kernel, in double precision on the
 // host.  It is only a launch order: every tile is rendered by the same kernel whatever its rank.
-static void compute_tile_order(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
-                               std::vector<uint32_t> &order, std::vector<uint32_t> &order_pos, uint32_t &order_active) {
+static void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                                   uint32_t *order, uint32_t *order_pos, uint32_t &order_active, int G) {
     const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
     const size_t n = (size_t)tx * ty;
     const double W = ctx->width, H = ctx->height;
-    std::vector<double> cost(n, 0.0);
-    auto mul = [&](const float *m, double x, double y, double z, double w, double o[4]) {
-        for (int r = 0; r < 4; r++) o[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
-    };
-    const double dims[3] = {(double)std::max(ctx->nx, 1u), (double)std::max(ctx->ny, 1u), (double)std::max(ctx->nz, 1u)};
-    for (uint32_t j = 0; j < ty; j++)
-        for (uint32_t i = 0; i < tx; i++) {
-            double c = 0.0;
-            for (int sy = 0; sy < 3; sy++)
-                for (int sx = 0; sx < 3; sx++) {
-                    double px = ox + (double)i * ts + (2 * sx + 1) * ts / 6.0, py = oy + (double)j * ts + (2 * sy + 1) * ts / 6.0;
-                    if (px < 0 || py < 0 || px >= W || py >= H) continue;
-                    double e[3], d[3], lo, hi;
-                    if (mode == VK_MODE_NAIVE_TRILINEAR) {
-                        double q[4];
-                        mul(cam + 20, 2.0 * px / W - 1.0, 1.0 - 2.0 * py / H, 1.0, 1.0, q);
-                        for (int k = 0; k < 3; k++) { e[k] = cam[k]; d[k] = q[k] / q[3] - e[k]; }
-                        lo = 0.0; hi = 1.0;
-                    } else {
-                        double a[4], b[4], sxn = 2.0 * px / W - 1.0, syn = (2.0 * py / H - 1.0) * -(H / W);
-                        mul(cam + 20, sxn, syn, 0.0, 1.0, a);
-                        mul(cam + 20, sxn, syn, 1.0, 1.0, b);
-                        for (int k = 0; k < 3; k++) { e[k] = a[k] / a[3]; d[k] = b[k] / b[3] - e[k]; }
-                        lo = -1.0; hi = 1.0;
-                    }
-                    double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-                    if (!(len > 0)) continue;
-                    double t0 = -1e300, t1 = 1e300, dtm = 1e300;
-                    for (int k = 0; k < 3; k++) {
-                        d[k] /= len;
-                        double inv = 1.0 / d[k], ta = (lo - e[k]) * inv, tb = (hi - e[k]) * inv;
-                        t0 = std::max(t0, std::min(ta, tb));
-                        t1 = std::min(t1, std::max(ta, tb));
-                        dtm = std::min(dtm, 1.0 / (dims[k] * std::fabs(d[k])));
-                    }
-                    t0 = std::max(t0, 0.0);
-                    if (t1 > t0 && dtm > 0) c += (t1 - t0) / dtm;
-                }
-            cost[(size_t)j * tx + i] = c;
-        }
-    order.resize(n);
-    for (size_t t = 0; t < n; t++) order[t] = (uint32_t)t;
-    // tiles that do not touch the cube's screen rectangle hold only clear-colour pixels: they sort last and
-    // are "inactive" -- never marched, never gathered (the root clears them in vk_untile)
+    // tiles that do not touch the cube's screen rectangle hold only clear-colour pixels: they sort last (in index
+    // order) and are "inactive" -- never marched, never gathered (the root clears them in vk_untile); no rays for them
     int32_t cr[4];
     cull_rect_cam(ctx, cam, mode, cr);
-    std::vector<unsigned char> active(n, 1);
-    uint32_t n_active = 0;
+    struct Key { double cost; uint32_t tile; };
+    std::vector<Key> act;
+    act.reserve(n);
+    const float *m = cam + 20;
+    const double dims[3] = {(double)std::max(ctx->nx, 1u), (double)std::max(ctx->ny, 1u), (double)std::max(ctx->nz, 1u)};
+    uint32_t n_inactive = 0;
     for (uint32_t j = 0; j < ty; j++)
         for (uint32_t i = 0; i < tx; i++) {
             const int64_t x0 = (int64_t)ox + (int64_t)i * ts, y0 = (int64_t)oy + (int64_t)j * ts;
-            const bool a = !(x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3]);
-            active[(size_t)j * tx + i] = a;
-            n_active += a;
+            const uint32_t tile = j * tx + i;
+            if (x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3]) { order[n - 1 - n_inactive++] = tile; continue; }  // (reversed below)
+            double c = 0.0;
+            for (int sy = 0; sy < G; sy++)
+                for (int sx = 0; sx < G; sx++) {
+                    const double px = (double)x0 + (2 * sx + 1) * ts / (2.0 * G), py = (double)y0 + (2 * sy + 1) * ts / (2.0 * G);
+                    if (px < 0 || py < 0 || px >= W || py >= H) continue;
+                    double e[3], d[3], lo, hi;
+                    if (mode == VK_MODE_NAIVE_TRILINEAR) {
+                        const double X = 2.0 * px / W - 1.0, Y = 1.0 - 2.0 * py / H;
+                        const double qw = 1.0 / (m[3] * X + m[7] * Y + m[11] + m[15]);
+                        for (int k = 0; k < 3; k++) { e[k] = cam[k]; d[k] = (m[k] * X + m[4 + k] * Y + m[8 + k] + m[12 + k]) * qw - e[k]; }
+                        lo = 0.0; hi = 1.0;
+                    } else {
+                        const double X = 2.0 * px / W - 1.0, Y = (2.0 * py / H - 1.0) * -(H / W);
+                        const double aw = 1.0 / (m[3] * X + m[7] * Y + m[15]), bw = 1.0 / (m[3] * X + m[7] * Y + m[11] + m[15]);
+                        for (int k = 0; k < 3; k++) {
+                            e[k] = (m[k] * X + m[4 + k] * Y + m[12 + k]) * aw;
+                            d[k] = (m[k] * X + m[4 + k] * Y + m[8 + k] + m[12 + k]) * bw - e[k];
+                        }
+                        lo = -1.0; hi = 1.0;
+                    }
+                    const double len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                    if (!(len2 > 0)) continue;
+                    // steps = (t1 - t0) / dt with t in units of |d| (the normalisation cancels): dt = min_k 1 / (dims_k |d_k|)
+                    double t0 = -1e300, t1 = 1e300, inv_dt = 0.0;
+                    for (int k = 0; k < 3; k++) {
+                        const double inv = 1.0 / d[k], ta = (lo - e[k]) * inv, tb = (hi - e[k]) * inv;
+                        t0 = std::max(t0, std::min(ta, tb));
+                        t1 = std::min(t1, std::max(ta, tb));
+                        inv_dt = std::max(inv_dt, dims[k] * std::fabs(d[k]));
+                    }
+                    t0 = std::max(t0, 0.0);
+                    if (t1 > t0 && inv_dt > 0) c += (t1 - t0) * inv_dt;
+                }
+            act.push_back({c, tile});
         }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        if (active[a] != active[b]) return active[a] > active[b];
-        return cost[a] > cost[b];
-    });
+    const uint32_t n_active = (uint32_t)act.size();
+    std::stable_sort(act.begin(), act.end(), [](const Key &a, const Key &b) { return a.cost > b.cost; });
+    for (uint32_t q = 0; q < n_active; q++) order[q] = act[q].tile;
+    std::reverse(order + n_active, order + n);  // inactive tiles in index order
     // Position q goes to XCD q % 8 (rank q % N first, when the frame is partitioned): dealt straight, bin 0
     // would receive the heaviest tile of every round of 8.  Reverse every other round (snake) so the bins'
     // sums even out; the active tiles stay in front.
-    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(order.begin() + g, order.begin() + g + 8);
+    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(order + g, order + g + 8);
     order_active = n_active;
-    order_pos.resize(n);
     for (size_t q = 0; q < n; q++) order_pos[order[q]] = (uint32_t)q;
+}
+
+static void compute_tile_order(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
+                               std::vector<uint32_t> &order, std::vector<uint32_t> &order_pos, uint32_t &order_active) {
+    const size_t n = (size_t)((rw + ts - 1) / ts) * ((rh + ts - 1) / ts);
+    order.resize(n); order_pos.resize(n);
+    compute_tile_order_raw(ctx, cam, mode, ox, oy, rw, rh, ts, order.data(), order_pos.data(), order_active, (int)ctx->order_rays);
 }
 
 static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
@@ -1274,19 +1277,37 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
     uint32_t *h_pos = h_order + (size_t)n_frames * n_tiles;
     uint32_t max_active = 0;
+    // The tile order depends on the camera (and the frame / volume shape).  It is written straight into the pinned
+    // staging block; a frame with the camera of the frame before it (or of the last frame of the previous batch) copies
+    // that frame's tables instead of casting the estimate rays again.
     std::vector<uint32_t> &order = ctx->batch_order, &pos = ctx->batch_pos;
-    uint32_t &n_active = ctx->batch_n_active;
+    // Estimate rays per tile: the 3 x 3 grid of the single-frame launches, or just the tile's centre ray when the grid
+    // spans >= 4 frames -- position-major over many frames the launch time no longer depends on the finer estimate
+    // (tools/order_rays.py) and the host's share drops from 40 to 10 us per camera, which is what an orbiting camera
+    // at N = 8 (13.6 us of march per frame and rank) needs.
+    const int G = n_frames >= 4 ? (int)ctx->order_rays_batch : (int)ctx->order_rays;
+    const uint32_t kk[8] = {(uint32_t)geo_mode, ts, ctx->width, ctx->height, ctx->nx, ctx->ny, ctx->nz, (uint32_t)G};
+    std::vector<unsigned char> key(144 + 32);
+    std::memcpy(key.data() + 144, kk, 32);
+    std::vector<uint32_t> actives(n_frames, 0u);
     for (uint32_t f = 0; f < n_frames; f++) {
         const float *c = cams + 36 * f;
-        // the tile order depends on the camera (and the frame / volume shape): recomputed only when that changes
-        std::vector<unsigned char> key(144 + 28);
-        std::memcpy(key.data(), c, 144);
-        const uint32_t kk[7] = {(uint32_t)geo_mode, ts, ctx->width, ctx->height, ctx->nx, ctx->ny, ctx->nz};
-        std::memcpy(key.data() + 144, kk, 28);
-        if (key != ctx->batch_key || order.size() != n_tiles) {
-            compute_tile_order(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, order, pos, n_active);
-            ctx->batch_key.swap(key);
+        uint32_t *fo = h_order + (size_t)f * n_tiles, *fp = h_pos + (size_t)f * n_tiles;
+        if (f > 0 && std::memcmp(c, c - 36, 144) == 0) {
+            std::memcpy(fo, fo - n_tiles, n_tiles * sizeof(uint32_t));
+            std::memcpy(fp, fp - n_tiles, n_tiles * sizeof(uint32_t));
+            actives[f] = actives[f - 1];
+        } else {
+            std::memcpy(key.data(), c, 144);
+            if (f == 0 && key == ctx->batch_key && order.size() == n_tiles) {
+                std::memcpy(fo, order.data(), n_tiles * sizeof(uint32_t));
+                std::memcpy(fp, pos.data(), n_tiles * sizeof(uint32_t));
+                actives[f] = ctx->batch_n_active;
+            } else {
+                compute_tile_order_raw(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, fo, fp, actives[f], G);
+            }
         }
+        const uint32_t n_active = actives[f];
         std::memcpy(fd[f].eye, c, 16);
         std::memcpy(fd[f].inv_proj, c + 20, 64);
         int32_t cr[4];
@@ -1296,9 +1317,15 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         // whole frames cover every tile (the kernel clears the inactive ones); a rank's share only the active ones
         fd[f].n_active = compact ? n_active : (uint32_t)n_tiles;
         fd[f].pad[0] = n_active; fd[f].pad[1] = 0;
-        std::memcpy(h_order + f * n_tiles, order.data(), n_tiles * sizeof(uint32_t));
-        std::memcpy(h_pos + f * n_tiles, pos.data(), n_tiles * sizeof(uint32_t));
         max_active = std::max(max_active, n_active);
+    }
+    {   // remember the last frame's tables for the next batch
+        const uint32_t l = n_frames - 1;
+        std::memcpy(key.data(), cams + 36 * l, 144);
+        ctx->batch_key = key;
+        order.assign(h_order + (size_t)l * n_tiles, h_order + (size_t)(l + 1) * n_tiles);
+        pos.assign(h_pos + (size_t)l * n_tiles, h_pos + (size_t)(l + 1) * n_tiles);
+        ctx->batch_n_active = actives[l];
     }
     const uint32_t root_skip = nranks > 1 ? ctx->root_skip : 0u;
     const uint32_t slots_active = deal_rounds(max_active, nranks, root_skip);
@@ -1660,6 +1687,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
+    else if (n == "order_rays") { ctx->order_rays = ctx->order_rays_batch = (uint32_t)std::min<double>(std::max<double>(value, 1), 8); ctx->batch_key.clear(); ctx->order_key.clear(); }
     else if (n == "naive_lds_pad") ctx->naive_lds_pad = (uint32_t)value;          // experiments: caps the cell kernels' waves per SIMD
     else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)
     else return fail(ctx, VK_ERR_INVALID, "vk_debug_set_param: unknown parameter " + n);
