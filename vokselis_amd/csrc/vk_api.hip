@@ -32,7 +32,7 @@ struct vk_ctx {
     void *vol = nullptr, *vol2 = nullptr;  // cells / dense voxels / pair
     void *scopy[3] = {nullptr, nullptr, nullptr};  // VK_LAYOUT_STAGED: one brick copy per slow axis
     StagedDesc sdesc{};
-    uint32_t stage_cap_bytes = 0, stage_slab_cells = 8, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
+    uint32_t stage_cap_bytes = 0, stage_slab_cells = 0, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
     uint8_t *dist = nullptr;
     uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
     size_t vol_bytes = 0;
@@ -762,15 +762,59 @@ static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     else { if (safe) launch_naive<VOL, false, true>(ctx, L, V, grid, count); else launch_naive<VOL, false, false>(ctx, L, V, grid, count); }
 }
 
+// LDS window per wave of the staged march: more LDS = thicker slabs (fewer rounds, each with its slab search, bounds
+// and fill) but fewer waves per CU.  The best budget depends on the view: what counts is the box an 8 x 8 pixel wave
+// sweeps per slab -- its footprint in cells (distance x pixel angle x n) plus the lateral drift of oblique rays -- and
+// the measured optimum (tools/staged_cameras.py: six cameras, C4 and C5) follows the bytes of that box for a slab of
+// T* = 4 cells (u8: at the VALU issue limit, occupancy first) or 6 cells (f16), in whole waves per CU between 5 KiB (8 waves
+// per SIMD) and 20 KiB (2): C5 from far away 5.83 -> 3.5 ms, from close by 38.4 -> 34.1 ms against a fixed 8 KiB.
+static uint32_t staged_cap_auto(const vk_ctx *ctx, const float *cam, bool u8, uint32_t *slab_cells) {
+    const uint32_t fallback = u8 ? 6144u : 10240u;
+    *slab_cells = u8 ? 6u : 8u;
+    if (!cam) return fallback;
+    const float *m = cam + 20;
+    const double W = ctx->width, H = ctx->height;
+    auto dir_of = [&](double px, double py, double d[3]) {
+        const double X = 2.0 * px / W - 1.0, Y = 1.0 - 2.0 * py / H;
+        const double qw = m[3] * X + m[7] * Y + m[11] + m[15];
+        double len = 0.0;
+        for (int k = 0; k < 3; k++) { d[k] = (m[k] * X + m[4 + k] * Y + m[8 + k] + m[12 + k]) / qw - cam[k]; len += d[k] * d[k]; }
+        len = std::sqrt(len);
+        for (int k = 0; k < 3; k++) d[k] /= len;
+        return len;
+    };
+    double a[3], b[3];
+    if (!(dir_of(0.5 * W, 0.5 * H, a) > 0.0) || !(dir_of(0.5 * W + 8.0, 0.5 * H + 8.0, b) > 0.0)) return fallback;
+    const double cosang = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    if (!std::isfinite(cosang)) return fallback;
+    const double ang = std::acos(std::min(1.0, std::max(-1.0, cosang))) / std::sqrt(2.0);  // 8 pixels along one image axis
+    const double to_c[3] = {0.5 - cam[0], 0.5 - cam[1], 0.5 - cam[2]};
+    const double dist = std::sqrt(to_c[0] * to_c[0] + to_c[1] * to_c[1] + to_c[2] * to_c[2]);
+    const double n[3] = {(double)ctx->nx, (double)ctx->ny, (double)ctx->nz};
+    // cells per step along each axis for the central ray; the largest is the slab axis S, then F = S+1, M = S+2 (vk_staged.hpp)
+    const double c[3] = {std::fabs(a[0]) * n[0], std::fabs(a[1]) * n[1], std::fabs(a[2]) * n[2]};
+    const int S = (c[0] >= c[1] && c[0] >= c[2]) ? 0 : (c[1] >= c[2] ? 1 : 2), F = (S + 1) % 3, M = (S + 2) % 3;
+    if (!(c[S] > 0.0) || !std::isfinite(dist)) return fallback;
+    const double Tstar = u8 ? 4.0 : 6.0;
+    const double rows = std::ceil(ang * dist * n[M] + c[M] / c[S] * Tstar + 3.0), cols = std::ceil(ang * dist * n[F] + c[F] / c[S] * Tstar + 3.0);
+    const double per_piece = u8 ? 16.0 : 8.0;
+    const double bytes = (Tstar + 1.0) * rows * std::ceil((cols + per_piece - 1.0) / per_piece) * 16.0;
+    if (!std::isfinite(bytes)) return fallback;
+    // a budget buys whole waves per CU (160 KiB of LDS, 4 SIMDs): the smallest of 32, 28, ... 8 waves' shares that holds the box
+    for (uint32_t waves = 32u; waves > 8u; waves -= 4u) {
+        const uint32_t cap = (163840u / waves) & ~15u;
+        if ((double)cap >= 0.95 * bytes) return cap;
+    }
+    return 20480u;
+}
+
 template <int VOL>
-static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
+static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count, const float *cam) {
     StagedDesc D = ctx->sdesc;
-    // LDS window per wave: more LDS = thicker slabs but fewer waves per CU; measured optimum (tools/staged_sweep.py):
-    // 8 KiB for u8 (C5), 10 KiB for f16 (C4: 2.30 ms against 2.39 at 12 KiB; 0.1 % of its rounds, at the far end, then
-    // fall back to one-cell slabs served from global memory)
-    const uint32_t cap_auto = VOL == VOL_S8U8 ? 8192u : 10240u;
+    uint32_t slab_auto = 8u;
+    const uint32_t cap_auto = staged_cap_auto(ctx, cam, VOL == VOL_S8U8, &slab_auto);
     D.cap_bytes = std::min(std::max((ctx->stage_cap_bytes ? ctx->stage_cap_bytes : cap_auto) & ~15u, 1024u), 65536u);
-    D.slab_cells = std::min(std::max(ctx->stage_slab_cells, 1u), 32u);
+    D.slab_cells = std::min(std::max(ctx->stage_slab_cells ? ctx->stage_slab_cells : slab_auto, 1u), 32u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (f16) {
         if (count) hipLaunchKernelGGL((raymarch_staged_kernel<VOL, OUT_RGBA16F, true>), dim3(grid), dim3(64), D.cap_bytes, ctx->stream, L, V, D);
@@ -1047,8 +1091,8 @@ static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_
             case VOL_PF16: launch_packed<VOL_PF16>(ctx, L, V, grid, count, skip, safe); break;
             case VOL_B9U8: launch_naive<VOL_B9U8, false, true>(ctx, L, V, grid, count); break;
             case VOL_B9F16: launch_naive<VOL_B9F16, false, true>(ctx, L, V, grid, count); break;
-            case VOL_S8U8: launch_staged<VOL_S8U8>(ctx, L, V, grid, count); break;
-            case VOL_S8F16: launch_staged<VOL_S8F16>(ctx, L, V, grid, count); break;
+            case VOL_S8U8: launch_staged<VOL_S8U8>(ctx, L, V, grid, count, reach_cam); break;
+            case VOL_S8F16: launch_staged<VOL_S8F16>(ctx, L, V, grid, count, reach_cam); break;
             case VOL_Q8: launch_naive<VOL_Q8, false, true>(ctx, L, V, grid, count); break;
             case VOL_QF16: launch_naive<VOL_QF16, false, true>(ctx, L, V, grid, count); break;
             case VOL_LINEAR_F16: launch_naive<VOL_LINEAR_F16, false, true>(ctx, L, V, grid, count); break;

@@ -377,7 +377,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
 // fs_main (raycast_naive.wgsl:83-125) on the staged layout.  Same ray set-up, output and counters as
 // raymarch_naive_kernel; no lane leaves before the march: all 64 take part in the reductions and the fills.
 template <int VOL, int OUT, bool COUNT>
-__global__ __launch_bounds__(64) void raymarch_staged_kernel(const LaunchDesc L, const VolumeDesc V, const StagedDesc D) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void raymarch_staged_kernel(const LaunchDesc L, const VolumeDesc V, const StagedDesc D) {
     static_assert(VOL == VOL_S8U8 || VOL == VOL_S8F16, "staged layouts");
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
