@@ -269,6 +269,8 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     const float inv = fit ? 1.0f / duS : 0.0f;
     const float ratM = (s[M] * fn[M]) * inv, ratF = (s[F] * fn[F]) * inv;  // lateral cells per cell of S
 
+    int Tprev = T0;
+    const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
     for (;;) {
         const bool live = fit && (t < t1 && A < 0.95f);
         if (__ballot(live) == 0ull) break;  // wave-uniform
@@ -277,7 +279,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         const int iS = cvt_floor_i32(uS);
         // the slab starts at the rearmost live ray
         const int sig = dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000);
-        int T = T0;
+        int T = min(T0, Tprev + 1);  // the box changes slowly from round to round: the search starts one above the last fit
         int clo = dir_up ? sig : sig - T + 1;
         const bool inslab = live && (uint32_t)(iS - clo) < (uint32_t)T;
         // lateral bounds of the rays in the slab: from here to the slab's far plane
@@ -303,6 +305,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
             if (fits || T == 1) break;
             T--;
         }
+        Tprev = T;
         if (fits) {
             // ---- fill: piece (slice, q) of the window [slow][mid][fast-piece] <- its 16 bytes in the copy.  A lane keeps its
             // (row, piece) of the slice, i.e. a 32-bit offset inside one layer of bricks, for every slice; the slice only
@@ -316,16 +319,26 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     const uint32_t f = q - m * Efp;
                     const uint32_t mm = (uint32_t)ilM + m;
                     const uint32_t voff = ((pf0 + f + npf * (mm >> 3)) << 10) | ((mm & 7u) << 4);
-                    for (uint32_t si = 0; si < Es; si++) {
-                        const uint32_t sv = (uint32_t)ilS + si;
-                        const unsigned char *sbase = base + (((uint64_t)(npf * nbm) * (uint64_t)(sv >> 3)) << 10) + ((sv & 7u) << 7);
-                        // global_load_lds_dwordx4 with the slice's base in a scalar pair and the lane's 32-bit offset: no vector
-                        // arithmetic per load (the builtin only takes a 64-bit per-lane address: one v_lshl_add_u64 each)
-                        const uint32_t lds_dst = win_lds + (si * slicePieces + j) * 16u;
-                        uint32_t keep_m0;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep_m0) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+                    // global_load_lds_dwordx4 with the slice's base in a scalar pair and the lane's 32-bit offset: no vector
+                    // arithmetic per load (the builtin only takes a 64-bit per-lane address: one v_lshl_add_u64 each).  The
+                    // base moves by 128 bytes per slice inside a layer of bricks and by the rest of the layer at a brick
+                    // boundary; M0 (the LDS destination) is saved and restored once around the slices.
+                    uint32_t sv = (uint32_t)ilS;
+                    const unsigned char *sbase = base + layerB * (uint64_t)(sv >> 3) + ((sv & 7u) << 7);
+                    uint32_t lds_dst = win_lds + j * 16u;
+                    uint32_t keep_m0;
+                    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+                    for (uint32_t si = 0; si < Es;) {
+                        const uint32_t run = min(8u - (sv & 7u), Es - si);  // slices left in this layer of bricks
+                        for (uint32_t k = 0; k < run; k++) {
+                            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+                            sbase += 128;
+                            lds_dst += slicePieces * 16u;
+                        }
+                        si += run; sv += run;
+                        sbase += layerB - 1024u;  // (from the end of this layer's 8 slices to the next layer's first)
                     }
+                    asm volatile("s_mov_b32 m0, %0" : : "s"(keep_m0) : "memory");
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
