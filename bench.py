@@ -181,8 +181,11 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         # LDS-limited waves loses its tail
         nb = 4 if key == "c4" else 2
         fr = torch.empty((nb, H, W, 4), dtype=torch.float16, device="cuda")
-        blob = cam.get_proj_view_matrix()
-        ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, [blob] * nb, fr.data_ptr(), tile_size=TILE), 3, warm=1) / nb
+        # consecutive frames of an orbit (yaw step 2 pi / 1024), not one camera repeated: identical frames in one launch
+        # share their brick fetches in L2 / Infinity Cache and run up to 20 % faster than any real frame stream
+        # (tools/big_batch_orbit.py); unrelated views in one launch gain nothing over single launches
+        blobs = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(nb)]
+        ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, blobs, fr.data_ptr(), tile_size=TILE), 3, warm=1) / nb
         del fr
         dims = (V.native.C.c_uint32 * 3)()
         lay, nbytes = V.native.C.c_int(), V.native.C.c_size_t()
@@ -198,7 +201,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
                 "frac": alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS}
         return {"dense_core": core, "workload": cfg["name"], "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
                 "algorithmic_bytes_per_launch": alg, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS, "volume_setup_s": setup,
-                "batch": {"frames_per_launch": nb, "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
                 "volume_device_bytes": nbytes.value, "kernel": "vk::raymarch_staged_kernel" if lay.value == 6 else "vk::raymarch_naive_kernel"}
     finally:

@@ -1155,7 +1155,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.trace = nullptr;
     L.frames = nullptr;
     L.n_frames = 1;
-    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u) | (ctx->wave_prio >= 2u ? 32u : 0u);
+    L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u);
     if (count && ctx->want_trace) {
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);
@@ -1395,7 +1395,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.compact = compact ? 1u : 0u;
     L.dt_scale = dt_scale;
     L.out = out;
-    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u) | (ctx->wave_prio >= 2u ? 32u : 0u);
+    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u);
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
     L.n_frames = n_frames;
     const int rc = dispatch_march(ctx, mode, L, flags, far_cam);

@@ -247,7 +247,7 @@ __device__ __forceinline__ float sample_global(const StagedDesc &D, const float 
 //    bounds the box) are marched from global memory after the others -- adjacent pixels do not produce such rays
 //    at any sane field of view; the path exists for safety.
 template <int VOL, int PERM, bool COUNT>
-__device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane, const float prio_full) {
+__device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane) {
     constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
     constexpr bool U8 = (VOL == VOL_S8U8);
     constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
@@ -269,16 +269,18 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     const float inv = fit ? 1.0f / duS : 0.0f;
     const float ratM = (s[M] * fn[M]) * inv, ratF = (s[F] * fn[F]) * inv;  // lateral cells per cell of S
 
-    int Tprev = T0;
+    int Tprev = T0, sig_next = 0;
+    bool have_sig = false;
     const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
     for (;;) {
         const bool live = fit && (t < t1 && A < 0.95f);
         if (__ballot(live) == 0ull) break;  // wave-uniform
-        if (prio_full > 0.0f) set_wave_priority(live, t, t1, dt, prio_full);  // by what is left of the longest ray
         const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
         const int iS = cvt_floor_i32(uS);
-        // the slab starts at the rearmost live ray
-        const int sig = dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000);
+        // The slab starts at the rearmost live ray -- found by a reduction in the first round and after a fallback round;
+        // after a marched slab every live ray has left it (or was ahead of it), so the cell behind its far plane is a valid
+        // start without looking (if the rearmost ray is further on, the slab only holds a few unused cells).
+        const int sig = have_sig ? sig_next : (dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000));
         int T = min(T0, Tprev + 1);  // the box changes slowly from round to round: the search starts one above the last fit
         int clo = dir_up ? sig : sig - T + 1;
         const bool inslab = live && (uint32_t)(iS - clo) < (uint32_t)T;
@@ -306,6 +308,8 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
             T--;
         }
         Tprev = T;
+        have_sig = fits;
+        sig_next = dir_up ? clo + T : clo - 1;
         if (fits) {
             // ---- fill: piece (slice, q) of the window [slow][mid][fast-piece] <- its 16 bytes in the copy.  A lane keeps its
             // (row, piece) of the slice, i.e. a 32-bit offset inside one layer of bricks, for every slice; the slice only
@@ -347,10 +351,10 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
             const int cbase = (kStagePad - ilS) * sliceB + (kStagePad - ilM) * rowB + (kStagePad - (int)(pf0 << VSH)) * BPV + (int)win_lds;
             if (live) {
                 for (;;) {
-                    if (!(t < t1 && A < 0.95f)) break;
                     const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
                     const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
-                    if ((uint32_t)(i[S] - clo) >= (uint32_t)T) break;  // left the slab (or has not reached it)
+                    // one exit test per step: the ray ended (:101, :115-117) or left the slab (or has not reached it)
+                    if (!((int)(t < t1) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
                     const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
                     const int a0 = mad_i24(i[S], sliceB, mad_i24(i[M], rowB, i[F] * BPV + cbase));  // |operands| < 2^23
                     uint32_t lo[4], hi[4];
@@ -441,14 +445,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int c0 = __popcll(__ballot(hit && mj == 0)), c1 = __popcll(__ballot(hit && mj == 1)), c2 = __popcll(__ballot(hit && mj == 2));
     Census cs;
     if (c0 + c1 + c2 != 0) {  // wave-uniform
-        const float full = fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale;
-        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, full);
-        const float prio_full = (L.debug_flags & 32u) ? full : 0.0f;  // re-evaluated in every round
+        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
-        if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane, prio_full);
-        else if (copy == 1u) march_staged_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane, prio_full);
-        else march_staged_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane, prio_full);
+        if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane);
+        else if (copy == 1u) march_staged_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane);
+        else march_staged_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane);
     }
     if (!pm.valid) return;
     float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
