@@ -213,6 +213,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 flow on a box with one GPU (tests/test_parity_gpu.py): every rank on device 0, rendezvous over
+    # gloo, tiles through torch.distributed.  Not a measurement -- the JSON says so.
+    rehearsal = os.environ.get("VK_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local_rank = 0
+        os.environ["VK_BENCH_TRANSPORT"] = "torch"
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -238,7 +244,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as G
 
@@ -292,12 +301,12 @@ def main():
             # not loadable, communicator refused) the same buffers go through torch.distributed's -- RCCL as well
             transport, why = os.environ.get("VK_BENCH_TRANSPORT", "rccl"), None
             try:
-                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport)
+                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport, via_host=rehearsal)
                 ok = 1
             except Exception as e:  # noqa: BLE001
                 btr, ok, why = None, 0, repr(e)
             if world > 1:
-                okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                okt = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
                 ok = int(okt.item())
             if not ok:
@@ -307,7 +316,7 @@ def main():
                     raise RuntimeError("tile gather could not be set up: %s" % why)
                 print("[bench] library communicator unavailable (%s): gathering through torch.distributed" % why, file=sys.stderr)
                 transport = "torch"
-                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport)
+                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport, via_host=rehearsal)
 
             def submit(timed):
                 btr.submit(blob)
@@ -330,7 +339,7 @@ def main():
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             if world > 1:
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             return el
@@ -376,6 +385,7 @@ def main():
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
                     **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
+                **({"rehearsal": "all ranks on ONE GPU over gloo: a test of the N > 1 flow, not a measurement"} if rehearsal else {}),
                 "repeats": repeats, "repeat_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
                 "device": info["device_name"], "volume_setup_s": t_volume,
             }

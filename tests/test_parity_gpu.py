@@ -1201,3 +1201,32 @@ def test_procedural_partition(V, O):
         assert (ctx.read_backbuffer().view(np.uint32) == want.view(np.uint32)).all()
     finally:
         ctx.close()
+
+
+def test_bench_multi_rank_flow_rehearsal(V, O):
+    """bench.py's N > 1 flow end to end under torch.distributed.run with two ranks -- both on this one GPU, rendezvous over
+    gloo, tiles through torch.distributed (VK_BENCH_REHEARSAL): the launch line the driver uses, the weighted deal, the
+    pipelined gather + un-tile, max-over-ranks timing and the JSON contract.  (The library's RCCL communicator needs one GPU
+    per rank: world 1 in test_batch_tile_renderer_world1_rccl, more on the driver's 8-GPU node.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, VK_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["warmup"] == 8 and d["unit"] == "Mray-steps/s" and d["value"] > 0
+    assert d["config"]["s_ref_per_frame"] == 148393048  # the C2 frame, as at N = 1
+    assert "rehearsal" in d and d["config"]["transport"].startswith("torch.distributed")
+    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
