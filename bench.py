@@ -469,6 +469,13 @@ def main():
                                                         "note": "wall time of 8 batches of 32 distinct cameras (one orbit); the views differ, so the march work per frame does too"}
             except Exception as e:
                 extras["orbit_one_camera_per_frame"] = {"error": str(e)}
+            try:
+                # the step after the hot path: present pass, backbuffer rgba16f -> window-sized RGBA8
+                ms_p = time_launches(ctx, lambda: ctx.render(), 50, warm=10)
+                extras["present_1080p"] = {"launch_ms": ms_p, "algorithmic_GBps": W * H * 12 / (ms_p * 1e-3) / 1e9, "frac": W * H * 12 / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "bilinear resample + ACES + sRGB + RGBA8, 8 B read + 4 B written per pixel; bound by its 3 divisions, 3 logs and 3 exps per pixel, not by HBM"}
+            except Exception as e:
+                extras["present_1080p"] = {"error": str(e)}
             it = 50
             p_ns = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_NO_SKIP)
             p_sk = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=V.RENDER_FORCE_SKIP)

@@ -1632,15 +1632,23 @@ __global__ __launch_bounds__(256) void present_kernel(const void *__restrict__ b
     float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy);
     int x0 = clampi(ix, 0, (int)bw - 1), x1 = clampi(ix + 1, 0, (int)bw - 1);
     int y0 = clampi(iy, 0, (int)bh - 1), y1 = clampi(iy + 1, 0, (int)bh - 1);
-    float4 t00 = load_px(bb, fmt, (size_t)y0 * bw + x0), t10 = load_px(bb, fmt, (size_t)y0 * bw + x1);
-    float4 t01 = load_px(bb, fmt, (size_t)y1 * bw + x0), t11 = load_px(bb, fmt, (size_t)y1 * bw + x1);
+    const float4 t00 = load_px(bb, fmt, (size_t)y0 * bw + x0);
+    float px[4] = {t00.x, t00.y, t00.z, t00.w};
+    if (fx != 0.0f || fy != 0.0f) {
+        // (a sample on a texel centre -- nearly every pixel when the backbuffer has the window's size -- has weights
+        // exactly (1, 0, 0, 0): fma(0, b - a, a) is a for finite taps, so the other three are not fetched)
+        const float4 t10 = load_px(bb, fmt, (size_t)y0 * bw + x1), t01 = load_px(bb, fmt, (size_t)y1 * bw + x0), t11 = load_px(bb, fmt, (size_t)y1 * bw + x1);
+        const float a1[4] = {t10.x, t10.y, t10.z, t10.w}, b0[4] = {t01.x, t01.y, t01.z, t01.w}, b1[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float a = fmaf(fx, a1[k] - px[k], px[k]), b = fmaf(fx, b1[k] - b0[k], b0[k]);
+            px[k] = fmaf(fy, b - a, a);
+        }
+    }
     float c[4];
-    const float a0[4] = {t00.x, t00.y, t00.z, t00.w}, a1[4] = {t10.x, t10.y, t10.z, t10.w};
-    const float b0[4] = {t01.x, t01.y, t01.z, t01.w}, b1[4] = {t11.x, t11.y, t11.z, t11.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        float a = fmaf(fx, a1[k] - a0[k], a0[k]), b = fmaf(fx, b1[k] - b0[k], b0[k]);
-        float v = fmaf(fy, b - a, a);
+        float v = px[k];
         if (k < 3) v = present_srgb(aces_film(v));
         c[k] = floorf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);
     }
