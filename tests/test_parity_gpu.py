@@ -430,6 +430,17 @@ def test_batch_tile_renderer_over_rccl_world1(V, O):
         assert sorted(got) == list(range(11))
         for k in range(11):
             assert (got[k] == want[k]).all(), k
+        # driven from torch's default stream: the renderer makes (and enters) a stream of its own
+        got.clear()
+        r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="rccl", on_batch=on_batch)
+        assert r.march_stream.cuda_stream != 0
+        for c in cams:
+            r.submit(c)
+        r.close()
+        ctx.set_stream(None)
+        assert sorted(got) == list(range(11))
+        for k in range(11):
+            assert (got[k] == want[k]).all(), k
     finally:
         ctx.close()
         if created:

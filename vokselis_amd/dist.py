@@ -132,10 +132,13 @@ class BatchTileRenderer:
         self.esize = 4 if bb.format == N.OUT_RGBA32F else 2
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self._group = group
-        # the march runs on torch's current stream (handle 0, the legacy default stream, reads as "the context's own")
+        # The march, the un-tile and (torch transport) the gather run on ONE stream of this object's choosing: torch's
+        # current stream when that is a real stream, else a new one (handle 0, the legacy default stream, would read as
+        # "the context's own" in the C-ABI).  Every call below enters it itself, so the caller's current stream does
+        # not matter; frames handed to on_batch are ordered on `march_stream`.
         cur = torch.cuda.current_stream()
         if not cur.cuda_stream:
-            raise RuntimeError("BatchTileRenderer needs a non-default torch stream: create it inside `with torch.cuda.stream(torch.cuda.Stream())`")
+            cur = torch.cuda.Stream()
         if ctx.stream_handle != cur.cuda_stream:
             ctx.set_stream(cur.cuda_stream)
         self.march_stream = cur
@@ -157,7 +160,8 @@ class BatchTileRenderer:
             raise ValueError("transport is 'rccl' or 'torch'")
         # The root also receives and un-tiles every frame: give it a lighter share of the march (rank 0 sits out every
         # k-th round of the deal).  "auto": k from this GPU's own timings of one batch's march and un-tile.
-        self.root_skip = self._calibrate_root_skip() if root_skip == "auto" else int(root_skip)
+        with torch.cuda.stream(self.march_stream):
+            self.root_skip = self._calibrate_root_skip() if root_skip == "auto" else int(root_skip)
         ctx.set_root_skip(self.root_skip if self.world > 1 else 0)
         self.cap = partition_slots(self.W, self.H, tile_size, self.world, self.root_skip if self.world > 1 else 0)
         shape = (self.cap, self.batch, tile_size, tile_size, 4)
@@ -218,13 +222,14 @@ class BatchTileRenderer:
             self._launch()
 
     def _launch(self):
-        torch = self.torch
+        with self.torch.cuda.stream(self.march_stream):
+            self._launch_on_stream()
+
+    def _launch_on_stream(self):
         s, cams = self._set, self._cams
         count = len(cams)
         if len(cams) < self.batch:  # a partial batch marches (and moves) whole batches: pad with the last camera
             cams = cams + [cams[-1]] * (self.batch - len(cams))
-        if torch.cuda.current_stream().cuda_stream != self.march_stream.cuda_stream:
-            raise RuntimeError("BatchTileRenderer must be driven on the torch stream it was created on")
         if self._used[s]:
             self.march_stream.wait_event(self.moved[s])  # the set's previous gather has read its tiles
         bid, act = render_batch(self.ctx, self.pipe, cams, self.send[s].data_ptr(), tile_size=self.ts, rank=self.rank, nranks=self.world,
@@ -266,7 +271,8 @@ class BatchTileRenderer:
     def flush(self):
         if self._cams:
             self._launch()
-        self._finish_pending()
+        with self.torch.cuda.stream(self.march_stream):
+            self._finish_pending()
 
     def close(self):
         self.flush()
