@@ -554,16 +554,10 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 px = px + sx; py = py + sy; pz = pz + sz;
                 t = t + dt;
                 if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
-                const float tstop8 = fmaf(-7.5f, dt, tstop);  // t < tstop8  =>  t + 7 dt < tstop as well
-                while (t < tstop8) {  // eight skipped iterations per trip: one compare and one branch for eight steps
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { px = px + sx; py = py + sy; pz = pz + sz; t = t + dt; }
-                    if (COUNT) { n_iter += 8; if (wave_leader()) w_inner++; }
-                }
-                if (t < tstop4) {
+                while (t < tstop4) {  // four skipped iterations per trip of the walk
 #pragma unroll
                     for (int j = 0; j < 4; j++) { px = px + sx; py = py + sy; pz = pz + sz; t = t + dt; }
-                    if (COUNT) { n_iter += 4; }
+                    if (COUNT) { n_iter += 4; if (wave_leader()) w_inner++; }
                 }
                 if (t < tstop2) {
                     px = px + sx; py = py + sy; pz = pz + sz;
