@@ -245,6 +245,50 @@ def test_partition_untile_equals_frame(V, O):
             ctx.close()
 
 
+def test_silhouette_cull_never_drops_a_hit_tile(V, O):
+    """Tiles the cube's projected silhouette (convex hull of its corners, 2 px of margin) cannot reach are never marched
+    nor gathered; the root clears them.  60 seeded cameras -- far, close, grazing, nearly axis-aligned, inside -- at two
+    tile sizes: compact partition + vk_untile must give the frame vk_render writes (which marches every pixel), bitwise."""
+    import torch
+
+    rng = np.random.default_rng(0xC011)
+    vol = O.volume_fog_u8(24, seed=5)
+    W, H = 208, 120
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        V.VolumeTexture(ctx, vol)
+        pipe = V.RaycastPipeline(dt_scale=1.0)
+        fewer = 0
+        for case in range(60):
+            zoom = float(rng.choice([0.3, 0.8, 1.0, 1.6, 3.0, 6.0]))
+            pitch = float(rng.uniform(-1.5, 1.5)) if case % 5 else float(rng.choice([0.0, 1e-3, 1.5]))
+            yaw = float(rng.uniform(0, 6.283)) if case % 7 else float(rng.choice([0.0, 1.5708, 3.1416]))
+            tgt = tuple(float(v) for v in (rng.uniform(0.2, 0.8, 3) if case % 3 else (0.5, 0.5, 0.5)))
+            ctx.set_camera_blob(O.camera_blob(zoom, pitch, yaw, tgt, W / H))
+            pipe.record(ctx)
+            whole = ctx.read_backbuffer()
+            for ts in (16, 32):
+                slots = V.partition_slots(W, H, ts, 1)
+                gathered = torch.full((1, slots, ts, ts, 4), float("nan"), dtype=torch.float32, device="cuda")
+                pipe.record_partition(ctx, ts, 0, 1, gathered.data_ptr())
+                n_active, _ = ctx.partition_active(ts, 1)
+                V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, 1, slots))
+                img = ctx.read_backbuffer()
+                assert (img == whole).all(), (case, ts, zoom, pitch, yaw, tgt)
+                # the hull is at least as tight as the bounding rectangle, and tighter somewhere
+                tx, ty = -(-W // ts), -(-H // ts)
+                hit = (whole[..., :3] != 0).any(axis=-1)
+                touched = sum(bool(hit[j * ts:(j + 1) * ts, i * ts:(i + 1) * ts].any()) for j in range(ty) for i in range(tx))
+                assert touched <= n_active <= tx * ty
+                if hit.any():
+                    ys, xs = np.nonzero(hit)
+                    rect = (xs.max() // ts - xs.min() // ts + 1) * (ys.max() // ts - ys.min() // ts + 1)
+                    fewer += n_active < rect
+        assert fewer > 10  # (the rectangle alone would keep all of them)
+    finally:
+        ctx.close()
+
+
 def test_render_batch_equals_single_frames(V, O):
     """vk_render_batch: B frames with B different cameras in ONE launch (whole frames at N = 1; per-rank compact
     tiles + vk_untile_batch for N in {1, 2, 3, 8} emulated on this GPU) -- every frame bitwise equal to vk_render's,
