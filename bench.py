@@ -230,6 +230,11 @@ def main():
     if not args.batch:
         # K frames in ceil(K / batch) launches of (almost) equal size: a padded last launch would march frames nobody counts
         n_launch = -(-args.steps // batch)
+        if world > 1 and args.steps >= 8:
+            # the gather of a launch hides behind the march of the next one: a timed region that is a single launch has
+            # nothing to hide behind (march, then wire, then un-tile, in series).  tools/small_k_emulation.py: at N = 8 two
+            # launches of 10 frames cost 2 x 0.21 ms of march against 0.31 ms for one of 20, and hide half of the wire time
+            n_launch = max(n_launch, 2)
         batch = -(-args.steps // n_launch)
 
     import torch
