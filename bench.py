@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--layout", default="auto", choices=["auto", "pairs", "packed", "bricked", "staged"], help="volume layout (auto: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
+    ap.add_argument("--no-preroll", action="store_true", help="skip the untimed pre-roll that brings the GPU to its sustained clocks before the W warm-up frames")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather driver even at N = 1 (the like-for-like baseline of the N > 1 lines)")
     return ap.parse_args()
 
@@ -349,6 +350,18 @@ def main():
                 el = float(tt.item())
             return el
 
+        # Pre-roll (untimed, every rank, the same path as the timed region): the GPU's clocks take ~10 ms of sustained load
+        # to settle -- five back-to-back regions of 20 frames ran 0.097, 0.092, 0.089, 0.086, 0.085 ms per frame in that
+        # order -- and the first RCCL transfers set up their channels.  One region of `batch` frames is measured (its
+        # maximum over ranks is the same number everywhere), then as many more as fill ~50 ms.  The W warm-up frames follow.
+        preroll_frames = 0
+        if not args.no_preroll:
+            timed_region(batch, False)  # (first use: tables, channels)
+            el = timed_region(batch, False)
+            n_pre = max(1, min(64, math.ceil(0.05 / max(el, 1e-4))))
+            for _ in range(n_pre):
+                timed_region(batch, False)
+            preroll_frames = (2 + n_pre) * batch
         timed_region(args.warmup, False) if args.warmup else None
         # SURVEY 8(d) asks for >= 100 timed frames: with a smaller K the region of exactly K frames is repeated
         repeats = max(1, min(10, math.ceil(100 / max(args.steps, 1))))
@@ -356,6 +369,7 @@ def main():
         for _ in range(repeats):
             del launch_ev[:]
             runs.append((timed_region(args.steps, True), [(a, b) for a, b in launch_ev]))
+        run_order_ms = [r[0] / args.steps * 1e3 for r in runs]  # in the order they ran
         runs.sort(key=lambda r: r[0])
         elapsed, evs = runs[len(runs) // 2]
         n_launch_frames = batch  # frames one launch spans
@@ -391,7 +405,7 @@ def main():
                     **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
                 **({"rehearsal": "all ranks on ONE GPU over gloo: a test of the N > 1 flow, not a measurement"} if rehearsal else {}),
-                "repeats": repeats, "repeat_ms_per_step": [r[0] / args.steps * 1e3 for r in runs],
+                "repeats": repeats, "repeat_ms_per_step": run_order_ms, "preroll_frames": preroll_frames,
                 "device": info["device_name"], "volume_setup_s": t_volume,
             }
             if launch_ms is not None:

@@ -1,0 +1,36 @@
+"""The reference's own use: one frame per camera, presented before the next (src/lib.rs:178-194).  Wall time per frame of
+set camera -> march -> present -> wait, with a camera that moves every frame, against the march kernel alone."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vokselis_amd as V
+
+W, H = 1920, 1080
+cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+V.VolumeTexture.generate_standin(ctx, (256,) * 3); ctx.update()
+p = V.RaycastPipeline(dt_scale=0.5)
+N = 300
+blobs = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 2048, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(N)]
+def loop(move, present, sync_each):
+    for j in range(20):
+        ctx.set_camera_blob(blobs[j]); p.record(ctx)
+    ctx.sync(); t0 = time.perf_counter()
+    for j in range(N):
+        if move: ctx.set_camera_blob(blobs[j])
+        p.record(ctx)
+        if present: ctx.render()
+        if sync_each: ctx.sync()
+    ctx.sync()
+    return (time.perf_counter() - t0) / N * 1e3
+for move in (False, True):
+    for present in (False, True):
+        for sync_each in (False, True):
+            print(json.dumps({"camera_moves": move, "present": present, "wait_every_frame": sync_each, "ms_per_frame": round(loop(move, present, sync_each), 4)}), flush=True)
+# host time of one render call with a new camera (no wait)
+ctx.sync(); t0 = time.perf_counter()
+for j in range(N):
+    ctx.set_camera_blob(blobs[j]); p.record(ctx)
+host = (time.perf_counter() - t0) / N * 1e3
+ctx.sync()
+print(json.dumps({"host_ms_per_call_new_camera (includes back-pressure)": round(host, 4)}))
+ctx.close()
