@@ -15,8 +15,9 @@ marched, rank 0 un-tiles (scaling: strong -- the frames are fixed).
 
 value   = S_ref * K / t  [Mray-steps/s]: S_ref = loop iterations the reference shader executes for one frame (with its
           alpha >= 0.95 early-out), counted by the kernel itself in an untimed counting launch and equal to the
-          oracle's count (tests).  Volume resident in HBM.  With K < 100 the timed region of exactly K frames is
-          repeated and the median repetition reported (`repeats`).
+          oracle's count (tests).  Volume resident in HBM.  The timed region of exactly K frames is repeated (3 times;
+          more while K < 100, up to 10) and the median repetition reported (`repeats`, `repeat_ms_per_step` in run
+          order); an untimed pre-roll of the same path brings the GPU to its sustained clocks first (`preroll_frames`).
 roofline: algorithmic bytes of one launch = batch * (S_sampled * B_step + W*H * 8 B), B_step = 8 B (8 u8 taps) or 16 B
           (f16), over the launch's mean duration from HIP events on the launch stream, against 8 TB/s.
           See DESIGN.md "Measurement".
@@ -364,7 +365,9 @@ def main():
             preroll_frames = (2 + n_pre) * batch
         timed_region(args.warmup, False) if args.warmup else None
         # SURVEY 8(d) asks for >= 100 timed frames: with a smaller K the region of exactly K frames is repeated
-        repeats = max(1, min(10, math.ceil(100 / max(args.steps, 1))))
+        # (and at least three times whatever K: a single region is at the mercy of one host hiccup -- a default run on a
+        # busy box once reported 27.5 ms of wall time around 20.3 ms of launches)
+        repeats = max(3, min(10, math.ceil(100 / max(args.steps, 1))))
         runs = []
         for _ in range(repeats):
             del launch_ev[:]

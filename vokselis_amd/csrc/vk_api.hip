@@ -1559,9 +1559,12 @@ int vk_gather_tiles(vk_ctx *ctx, const void *send, void *recv, size_t n_pixels, 
         if (r + (size_t)root * bytes != send) HIP_TRY(ctx, hipMemcpyAsync(r + (size_t)root * bytes, send, bytes, hipMemcpyDeviceToDevice, st));
         if (ctx->comm_size > 1) {
             NCCL_TRY(ctx, g_rccl.GroupStart());
-            for (int p = 0; p < ctx->comm_size; p++)
-                if (p != root) NCCL_TRY(ctx, g_rccl.Recv(r + (size_t)p * bytes, bytes, ncclUint8, p, ctx->comm, st));
-            NCCL_TRY(ctx, g_rccl.GroupEnd());
+            ncclResult_t bad = ncclSuccess;  // (an error inside the group still closes it: a group left open would swallow every later call)
+            for (int p = 0; p < ctx->comm_size && bad == ncclSuccess; p++)
+                if (p != root) bad = g_rccl.Recv(r + (size_t)p * bytes, bytes, ncclUint8, p, ctx->comm, st);
+            const ncclResult_t end = g_rccl.GroupEnd();
+            if (bad != ncclSuccess) return fail(ctx, VK_ERR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(bad));
+            if (end != ncclSuccess) return fail(ctx, VK_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(end));
         }
     } else {
         NCCL_TRY(ctx, g_rccl.Send(send, bytes, ncclUint8, root, ctx->comm, st));
