@@ -565,6 +565,15 @@ def main():
                     gb = (ss * 16 + 1280 * 720 * B_RAY) / (ms * 1e-3) / 1e9
                     extras["xor_compute_nearest_720p"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                           "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+                    # the same frame eight per launch: what the kernel does once the machine is full (a single 720p frame
+                    # is 14 400 waves, less than two rounds of the 8192 wave slots)
+                    xfr = torch.empty((8, 720, 1280, 4), dtype=torch.float16, device="cuda")
+                    xblob = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), 1280 / 720).get_proj_view_matrix()
+                    msb = time_launches(cx, lambda: V.render_batch(cx, pc, [xblob] * 8, xfr.data_ptr(), tile_size=TILE), 12, warm=4)
+                    gbb = (ss * 16 + 1280 * 720 * B_RAY) * 8 / (msb * 1e-3) / 1e9
+                    extras["xor_compute_nearest_720p_batch8"] = {"launch_ms": msb, "frames_per_launch": 8, "Mray_steps_per_s": sr * 8 / msb / 1e3,
+                                                                 "achieved_GBps": gbb, "frac": gbb / HBM_PEAK_GBS}
+                    del xfr
                 finally:
                     cx.close()
             except Exception as e:  # a side measurement must not take the headline down

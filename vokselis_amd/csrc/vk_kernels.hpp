@@ -1097,21 +1097,27 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
             float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
             float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
             n_iter++;
-            float sh = fmaxf(0.0f, (0.0f * n0 + -1.0f * n1) + 0.0f * n2);
+            // The shader's literal expressions (kept word for word in raymarch_compute_kernel below, which the tests hold
+            // this kernel to bit for bit) carry terms that are zero for every finite record: dot((0,-1,0), n) is -n.y,
+            // mix(shade, bl * (0,0,0.6), 0.2) has zero red and green contributions from bl, and clear.rgb * clear.a * (1 - a)
+            // is 0 * (1 - a).  IEEE arithmetic forbids the compiler to drop them (0 * x is NaN for an infinite x); with finite
+            // taps they only ever add a zero to a non-zero accumulator, so leaving them out changes no bit: 15 of the step's
+            // 85 instructions.  A volume with infinities or NaNs renders differently from the literal form.
+            float sh = fmaxf(0.0f, -n1);
             float va = (vc3 * vc3) * vc3;
             va = smoothstepf(0.0f, 0.7f, va);
             float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
             float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
             float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
             float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
-            float sh0 = sh * (1.0f - 0.2f) + (bl * 0.0f) * 0.2f;
+            float sh0 = sh * (1.0f - 0.2f);
             float sh1 = sh0;
             float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
             float w = (1.0f - A) * va;
-            C[0] = (C[0] + w * col0 * sh0) + clr[0] * 0.0f * (1.0f - va);
-            C[1] = (C[1] + w * col1 * sh1) + clr[1] * 0.0f * (1.0f - va);
-            C[2] = (C[2] + w * col2 * sh2) + clr[2] * 0.0f * (1.0f - va);
-            A = A + w * (1.0f - 0.0f);
+            C[0] = C[0] + w * col0 * sh0;
+            C[1] = C[1] + w * col1 * sh1;
+            C[2] = C[2] + w * col2 * sh2;
+            A = A + w;
             if (A >= 0.95f) break;
             t = tn;
             if (!(t < t1)) break;
