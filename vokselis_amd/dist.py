@@ -147,11 +147,17 @@ class BatchTileRenderer:
         if transport == "rccl":
             # the library's own communicator: rank 0 makes the id, torch.distributed (already up) ships its 128 bytes
             idbuf = (C.c_ubyte * 128)()
+            obj = [None]
             if self.rank == 0:
-                N.check(None, N.lib().vk_comm_unique_id(idbuf))
-            obj = [bytes(idbuf)]
+                try:  # a failure here must still reach the broadcast: the other ranks are waiting in it
+                    N.check(None, N.lib().vk_comm_unique_id(idbuf))
+                    obj = [bytes(idbuf)]
+                except Exception as e:  # noqa: BLE001
+                    obj = ["rank 0 could not make a communicator id: %r" % (e,)]
             if self.world > 1:
                 dist.broadcast_object_list(obj, src=0, group=group)
+            if not isinstance(obj[0], bytes):
+                raise RuntimeError(obj[0])
             N.check(ctx.handle, N.lib().vk_comm_init_rank(ctx.handle, obj[0], self.rank, self.world))
             self.tg = None
         elif transport == "torch":
