@@ -914,6 +914,8 @@ def test_error_behaviour(V, O, cameras, golden_volumes):
             ctx.set_camera_blob(bad.tobytes())
         with pytest.raises(V.VokselisError, match="no camera"):  # a rejected blob does not linger
             pipe.record(ctx)
+        with pytest.raises(ValueError, match="144 bytes"):  # a short buffer never reaches the C side
+            ctx.set_camera_blob(cameras["bonsai_1x1"][:100])
         ctx.set_camera_blob(cameras["bonsai_1x1"])
         pipe.record(ctx, (0, 0, 0, 0))  # empty tile is a no-op
         info = ctx.get_info()

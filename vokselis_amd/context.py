@@ -180,7 +180,9 @@ class Context:
         self.stream_handle = hip_stream
 
     def set_camera_blob(self, blob: bytes):
-        N.check(self._h, N.lib().vk_set_camera(self._h, blob))
+        if len(blob) != 144:  # the C side reads exactly one CameraUniform (src/camera.rs:5-11)
+            raise ValueError("a camera blob is 144 bytes, got %d" % len(blob))
+        N.check(self._h, N.lib().vk_set_camera(self._h, bytes(blob)))
         self.camera_blob = bytes(blob)
         self._first_frame = False
         self.camera_epoch += 1
@@ -351,6 +353,8 @@ class RaycastPipeline:
 def render_batch(ctx: Context, pipe: RaycastPipeline, cameras, out_ptr: int, *, tile_size: int = 64, rank: int = 0, nranks: int = 1,
                  compact: bool = False, slot_capacity: int = 0):
     """vk_render_batch: len(cameras) frames (144-byte blobs) in one launch.  Returns (batch_id, active slots per rank)."""
+    if not cameras or any(len(c) != 144 for c in cameras):
+        raise ValueError("render_batch: every camera is one 144-byte CameraUniform blob")
     blob = b"".join(cameras)
     n = len(blob) // 144
     bid, act = C.c_uint32(), C.c_uint32()
