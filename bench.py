@@ -75,10 +75,18 @@ def parse():
     return ap.parse_args()
 
 
-def time_launches(ctx, fn, iters, warm=3, groups=3):
+def time_launches(ctx, fn, iters, warm=3, groups=3, min_warm_ms=40.0):
     """Mean duration of one call of fn() from HIP events on the launch stream: the best of `groups` back-to-back groups
-    of `iters` calls (the first launches after a new volume, and the odd group, run at lower clocks)."""
+    of `iters` calls, after `warm` calls and as many more as fill `min_warm_ms` of GPU time (the clocks need ~10 ms of
+    sustained load to settle, and a side measurement may follow seconds of host-only work)."""
     for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.timer_begin()
+    fn()
+    ctx.timer_end()
+    one = max(ctx.timer_elapsed_ms(), 1e-3)
+    for _ in range(min(200, int(min_warm_ms / one))):
         fn()
     ctx.sync()
     best = None
