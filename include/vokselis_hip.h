@@ -159,6 +159,12 @@ int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint
 int vk_partition_root_skip(vk_ctx *ctx, uint32_t root_skip);
 int vk_partition_slots_weighted(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t root_skip,
                                 uint32_t *n_slots);
+/* The tiles a partition marches and moves ("active"): those the box's projected silhouette -- the convex hull of its 8
+ * corners under this camera, 2 px of margin -- can reach; every other tile holds only the clear colour
+ * (examples/bonsai/main.rs:41) and is cleared by the root.  Pure host arithmetic, no context: active[] receives
+ * tiles_x * tiles_y bytes (row-major, 1 = active).  vk_partition_active reports the same count for a context's camera. */
+int vk_tiles_active(const void *camera144, int mode, uint32_t width, uint32_t height, uint32_t tile_size,
+                    unsigned char *active, uint32_t *n_active);
 int vk_render_partition(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                         float dt_scale, uint32_t flags, void *compact_out);
 /* The partition deals tiles heaviest-first (a launch/balance heuristic derived from the camera):

@@ -121,6 +121,46 @@ def test_partition_bookkeeping():
     assert (720 // 256 + 1, 1280 // 256 + 1) == (3, 6)
 
 
+def test_active_tiles_cover_every_ray_that_hits_the_box(hip_built, O):
+    """vk_tiles_active (pure host arithmetic: the box's projected silhouette with 2 px of margin) against the oracle's own
+    ray / box test: a tile that holds a pixel whose ray enters the box must be active -- 240 seeded cameras (far, close,
+    grazing, nearly axis-aligned, off-centre targets, inside the box), two tile sizes.  And the silhouette is tighter than
+    the bounding rectangle round 1 used."""
+    rng = np.random.default_rng(0xAC71)
+    W, H = 176, 104
+    vol = np.full((2, 2, 2), 200, np.uint8)  # every ray that enters the box takes at least one step
+    tighter = 0
+    for case in range(240):
+        zoom = float(rng.choice([0.2, 0.45, 0.8, 1.0, 1.6, 3.0, 7.0]))
+        pitch = float(rng.uniform(-1.55, 1.55)) if case % 5 else float(rng.choice([0.0, 1e-3, -1e-3, 1.55]))
+        yaw = float(rng.uniform(0, 6.283)) if case % 7 else float(rng.choice([0.0, 1.5708, 3.1416, 0.7854]))
+        tgt = tuple(float(v) for v in (rng.uniform(0.0, 1.0, 3) if case % 3 else (0.5, 0.5, 0.5)))
+        blob = O.camera_blob(zoom, pitch, yaw, tgt, W / H)
+        _, steps, _ = O.render(blob, vol, W, H, dt_scale=1.0)
+        hit = steps > 0
+        for ts in (8, 32):
+            tx, ty = -(-W // ts), -(-H // ts)
+            act = (C.c_ubyte * (tx * ty))()
+            n = C.c_uint32()
+            assert hip_built.vk_tiles_active(blob, 0, W, H, ts, act, C.byref(n)) == 0
+            act = np.frombuffer(act, np.uint8).reshape(ty, tx).astype(bool)
+            assert n.value == act.sum()
+            touched = np.zeros((ty, tx), bool)
+            for j in range(ty):
+                for i in range(tx):
+                    touched[j, i] = hit[j * ts:(j + 1) * ts, i * ts:(i + 1) * ts].any()
+            assert not (touched & ~act).any(), (case, ts, zoom, pitch, yaw, tgt)
+            if hit.any() and ts == 8:
+                ys, xs = np.nonzero(touched)
+                rect = (xs.max() - xs.min() + 1) * (ys.max() - ys.min() + 1)
+                tighter += act.sum() < rect
+    assert tighter > 60
+    # the compute twin's box is [-1, 1]^3 under another ray generator: every tile is active there
+    act = (C.c_ubyte * 9)()
+    assert hip_built.vk_tiles_active(O.camera_blob(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), 1.0), 1, 24, 24, 8, act, None) == 0 and all(act)
+    assert hip_built.vk_tiles_active(None, 0, 24, 24, 8, act, None) != 0 and hip_built.vk_tiles_active(blob, 0, 24, 24, 12, act, None) != 0
+
+
 def test_untile_reference_roundtrip():
     from vokselis_amd import dist as D
 

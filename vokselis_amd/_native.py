@@ -44,6 +44,7 @@ SYMBOLS = {
     "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
     "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
     "vk_partition_slots_weighted": (C.c_int, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "vk_tiles_active": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, C.POINTER(C.c_ubyte), C.POINTER(_u32)]),
     "vk_partition_root_skip": (C.c_int, [_vp, _u32]),
     "vk_render_partition": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),
     "vk_partition_order": (C.c_int, [_vp, C.c_int, _u32, C.POINTER(_u32), _u32]),

@@ -828,8 +828,8 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
 // Screen-space bounding rectangle of the unit cube (NAIVE mode): the 8 corners projected with
 // proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
 // Pixels outside [x0,x1) x [y0,y1) cannot hit the box.
-static void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]) {
-    r[0] = 0; r[1] = 0; r[2] = (int32_t)ctx->width; r[3] = (int32_t)ctx->height;
+static void cull_rect_wh(uint32_t W, uint32_t H, const float *cam, int mode, int32_t r[4]) {
+    r[0] = 0; r[1] = 0; r[2] = (int32_t)W; r[3] = (int32_t)H;
     if (mode != VK_MODE_NAIVE_TRILINEAR) return;
     const float *pv = cam + 4;
     double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
@@ -838,15 +838,16 @@ static void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t
         const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
         const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
         if (!(cw > 1e-6)) return;
-        const double sx = (cx / cw * 0.5 + 0.5) * ctx->width, sy = (0.5 - cy / cw * 0.5) * ctx->height;
+        const double sx = (cx / cw * 0.5 + 0.5) * W, sy = (0.5 - cy / cw * 0.5) * H;
         x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
     }
     if (!(std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1))) return;
     r[0] = (int32_t)std::max(0.0, std::floor(x0) - 2.0);
     r[1] = (int32_t)std::max(0.0, std::floor(y0) - 2.0);
-    r[2] = (int32_t)std::min((double)ctx->width, std::ceil(x1) + 2.0);
-    r[3] = (int32_t)std::min((double)ctx->height, std::ceil(y1) + 2.0);
+    r[2] = (int32_t)std::min((double)W, std::ceil(x1) + 2.0);
+    r[3] = (int32_t)std::min((double)H, std::ceil(y1) + 2.0);
 }
+static void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]) { cull_rect_wh(ctx->width, ctx->height, cam, mode, r); }
 
 static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) { cull_rect_cam(ctx, ctx->camera, mode, r); }
 
@@ -856,7 +857,7 @@ static void cull_rect(const vk_ctx *ctx, int mode, int32_t r[4]) { cull_rect_cam
 // 288 of C2's 510 tiles; the hull keeps the ones a ray can actually hit.  n = 0: no hull (a corner behind the eye
 // plane, or another mode) -- the rectangle decides alone.
 struct CullHull { int n = 0; double x[16], y[16]; };
-static void cull_hull_cam(const vk_ctx *ctx, const float *cam, int mode, CullHull &h) {
+static void cull_hull_wh(uint32_t W, uint32_t H, const float *cam, int mode, CullHull &h) {
     h.n = 0;
     if (mode != VK_MODE_NAIVE_TRILINEAR) return;
     const float *pv = cam + 4;
@@ -866,7 +867,7 @@ static void cull_hull_cam(const vk_ctx *ctx, const float *cam, int mode, CullHul
         const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
         const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
         if (!(cw > 1e-6)) return;
-        p[c] = {(cx / cw * 0.5 + 0.5) * ctx->width, (0.5 - cy / cw * 0.5) * ctx->height};
+        p[c] = {(cx / cw * 0.5 + 0.5) * W, (0.5 - cy / cw * 0.5) * H};
         if (!(std::isfinite(p[c].first) && std::isfinite(p[c].second))) return;
     }
     std::sort(p, p + 8);
@@ -882,6 +883,9 @@ static void cull_hull_cam(const vk_ctx *ctx, const float *cam, int mode, CullHul
     h.n = k;
     for (int i = 0; i < k; i++) { h.x[i] = hull[i].first; h.y[i] = hull[i].second; }
 }
+// (forward) the tile-level decision, shared by the tile order and vk_tiles_active
+static bool tile_is_inactive(const int32_t cr[4], const CullHull &hull, int64_t x0, int64_t y0, uint32_t ts);
+
 // true when some hull edge has the whole rectangle [x0,x1] x [y0,y1] more than `pad` pixels on its outer side
 static bool hull_separates(const CullHull &h, double x0, double y0, double x1, double y1, double pad) {
     for (int i = 0; i < h.n; i++) {
@@ -896,6 +900,11 @@ static bool hull_separates(const CullHull &h, double x0, double y0, double x1, d
         if (std::max(std::max(d0, d1), std::max(d2, d3)) < -pad * len) return true;
     }
     return false;
+}
+
+static bool tile_is_inactive(const int32_t cr[4], const CullHull &hull, int64_t x0, int64_t y0, uint32_t ts) {
+    return x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3] ||
+           (hull.n && hull_separates(hull, (double)x0, (double)y0, (double)(x0 + ts), (double)(y0 + ts), 2.0));
 }
 
 // Tiles are dealt to the launch (and, at N > 1, to the ranks) heaviest first.  The frame is ~70 %
@@ -914,7 +923,7 @@ static void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode
     int32_t cr[4];
     cull_rect_cam(ctx, cam, mode, cr);
     CullHull hull;
-    cull_hull_cam(ctx, cam, mode, hull);
+    cull_hull_wh(ctx->width, ctx->height, cam, mode, hull);
     struct Key { double cost; uint32_t tile; };
     std::vector<Key> act;
     act.reserve(n);
@@ -925,8 +934,7 @@ static void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode
         for (uint32_t i = 0; i < tx; i++) {
             const int64_t x0 = (int64_t)ox + (int64_t)i * ts, y0 = (int64_t)oy + (int64_t)j * ts;
             const uint32_t tile = j * tx + i;
-            if (x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3] ||
-                (hull.n && hull_separates(hull, (double)x0, (double)y0, (double)(x0 + ts), (double)(y0 + ts), 2.0))) { order[n - 1 - n_inactive++] = tile; continue; }  // (reversed below)
+            if (tile_is_inactive(cr, hull, x0, y0, ts)) { order[n - 1 - n_inactive++] = tile; continue; }  // (reversed below)
             double c = 0.0;
             for (int sy = 0; sy < G; sy++)
                 for (int sx = 0; sx < G; sx++) {
@@ -1238,6 +1246,32 @@ int vk_partition_slots_weighted(uint32_t width, uint32_t height, uint32_t tile_s
     if (!n_slots || tile_size == 0 || (tile_size & 7u) || nranks == 0 || width == 0 || height == 0 || root_skip == 1) return VK_ERR_INVALID;
     uint64_t tiles = (uint64_t)((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
     *n_slots = deal_rounds((uint32_t)tiles, nranks, nranks > 1 ? root_skip : 0u);
+    return VK_OK;
+}
+
+// Which tiles of a width x height frame can hold a pixel whose ray hits the volume's box under this camera: the decision
+// every partition makes (inactive tiles are never marched nor gathered; the root clears them).  Pure host arithmetic, no
+// context: active[tile] (row-major, tiles_x * tiles_y bytes) is 1 or 0.
+int vk_tiles_active(const void *camera144, int mode, uint32_t width, uint32_t height, uint32_t tile_size, unsigned char *active, uint32_t *n_active) {
+    if (!camera144 || !active || tile_size == 0 || (tile_size & 7u) || width == 0 || height == 0) return VK_ERR_INVALID;
+    if (mode != VK_MODE_NAIVE_TRILINEAR && mode != VK_MODE_COMPUTE_NEAREST && mode != VK_MODE_PROCEDURAL) return VK_ERR_INVALID;
+    float cam[36];
+    std::memcpy(cam, camera144, 144);
+    for (float v : cam) if (!std::isfinite(v)) return VK_ERR_INVALID;
+    const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
+    int32_t cr[4];
+    cull_rect_wh(width, height, cam, geo_mode, cr);
+    CullHull hull;
+    cull_hull_wh(width, height, cam, geo_mode, hull);
+    const uint32_t tx = (width + tile_size - 1) / tile_size, ty = (height + tile_size - 1) / tile_size;
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < ty; j++)
+        for (uint32_t i = 0; i < tx; i++) {
+            const bool on = !tile_is_inactive(cr, hull, (int64_t)i * tile_size, (int64_t)j * tile_size, tile_size);
+            active[(size_t)j * tx + i] = on ? 1 : 0;
+            n += on;
+        }
+    if (n_active) *n_active = n;
     return VK_OK;
 }
 
