@@ -88,6 +88,10 @@ struct vk_ctx {
     std::vector<unsigned char> batch_key;
     std::vector<uint32_t> batch_order, batch_pos;
     uint32_t batch_n_active = 0;
+    // Skip kernels: steps a walk may take in a trip in which other lanes sample / in which every lane walks (0: no cap).
+    // tools/walk_cap_sweep.py: 8 / 12 -- C2 0.0806 -> 0.0728 ms per frame in batches, 0.1625 -> 0.1555 single; a fog with
+    // 80 % of its 16^3 blocks knocked out 0.161 -> 0.135.  Multiples of the walk loop's four steps do best.
+    uint32_t walk_cap = 8, walk_cap_all = 12;
     uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
     uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames
     uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements
@@ -1215,6 +1219,8 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.frames = nullptr;
     L.n_frames = 1;
     L.debug_flags = ((flags & VK_RENDER_DEBUG_TRIPS) ? 1u : 0u) | ((flags & VK_RENDER_DEBUG_FALLBACK) ? 2u : 0u) | ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u);
+    L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
+    L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     if (count && ctx->want_trace) {
         if (ctx->trace_blocks < n_blocks) {
             if (ctx->trace) (void)hipFree(ctx->trace);
@@ -1481,6 +1487,8 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.dt_scale = dt_scale;
     L.out = out;
     L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u);
+    L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
+    L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
     L.n_frames = n_frames;
     const int rc = dispatch_march(ctx, mode, L, flags, far_cam);
@@ -1819,6 +1827,8 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
+    else if (n == "walk_cap") ctx->walk_cap = (uint32_t)value;
+    else if (n == "walk_cap_all") ctx->walk_cap_all = (uint32_t)value;
     else if (n == "order_rays") { ctx->order_rays = ctx->order_rays_batch = (uint32_t)std::min<double>(std::max<double>(value, 1), 8); ctx->batch_key.clear(); ctx->order_key.clear(); }
     else if (n == "naive_lds_pad") ctx->naive_lds_pad = (uint32_t)value;          // experiments: caps the cell kernels' waves per SIMD
     else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)

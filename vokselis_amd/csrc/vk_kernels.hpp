@@ -102,6 +102,8 @@ struct LaunchDesc {
     // (the leading active slots of every frame) are one contiguous prefix; full frames are [frame][H][W].
     const FrameDesc *frames;
     uint32_t n_frames;
+    float walk_cap;                // skip kernels: steps a walk may take in a trip in which other lanes sample (+inf: no cap)
+    float walk_cap_all;            // ... and in a trip in which every lane walks
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------
@@ -467,7 +469,7 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 // inside the cell array: no clamp.
 template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false>
 __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs,
-                                      const uint32_t *lut = nullptr) {
+                                      const uint32_t *lut = nullptr, const float walk_cap = __builtin_inff(), const float walk_cap_all = __builtin_inff()) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
     constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
     float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
@@ -534,6 +536,13 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 coff = SKIP ? (uint32_t)(idx << V.sh_x) : idx;
                 if (SKIP) d = V.dist[idx + doff];
             }
+            // A trip in which some lanes sample is paced by them: whatever a walker covers beyond a few steps it covers while
+            // the samplers -- and every walker with a shorter walk -- wait for the longest walk of the wave (the walk loop ran
+            // 3.9 iterations of four steps per trip with 19 of 64 lanes active).  In such a trip walks are capped; the walker
+            // probes again next trip, which the wave makes anyway.  Any stop is exact: what is not skipped now is probed again.
+            // (One compare serves the branch and the wave-level test; the cap is a scalar.)
+            const unsigned long long walkers = SKIP ? __ballot(d != 0) : 0ull;
+            const float cap_now = (walkers != __ballot(true)) ? walk_cap : walk_cap_all;
             if (SKIP && d != 0) {
                 if (BOUNDED) cs.skips++;
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
@@ -548,7 +557,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 // f32 additions in the same order) while t < tstop.  tstop <= t1, so every skipped
                 // iteration passed the reference's `t < t1` test on the very same t; and t_j < tstop
                 // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
-                const float tstop = fminf(fmaf(fminf(fminf(rx, ry), rz), dt, t), t1q);
+                float rmin = fminf(fminf(rx, ry), rz);
+                asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
+                const float tstop = fminf(fmaf(rmin, dt, t), t1q);
                 const float tstop2 = fmaf(-1.5f, dt, tstop);  // t < tstop2  =>  t + dt < tstop as well
                 const float tstop4 = fmaf(-3.5f, dt, tstop);  // t < tstop4  =>  t + 3 dt < tstop as well
                 px = px + sx; py = py + sy; pz = pz + sz;
@@ -929,7 +940,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                 uint32_t stretch = stretch0;
                 for (;;) {
                     cs.skips = 0;
-                    bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr);
+                    bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
                     const unsigned long long live = __ballot(alive);
                     if (live == 0ull) break;
                     if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = stretch0; continue; }
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     stretch = min(stretch * 2u, 512u);
                 }
             } else {
-                march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr);
+                march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
             }
         }
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);
