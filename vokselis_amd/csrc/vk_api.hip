@@ -528,8 +528,8 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         nb.empty_fraction = (double)ne / (double)n_cells;
     }
     // Distance maps.  Eight one-sided maps (one per ray octant) when skipping will be on by default
-    // (>= 30 % empty cells) and they stay <= 2 GiB; otherwise one isotropic map serves every octant.
-    const bool octants = nb.empty_fraction >= 0.30 && n_cells <= (1ull << 28);  // the default policy skips from 30 % empty cells
+    // or may well be forced on (>= 30 % empty cells) and they stay <= 2 GiB; otherwise one isotropic map serves every octant.
+    const bool octants = nb.empty_fraction >= 0.30 && n_cells <= (1ull << 28);  // (the default policy skips from 45 %)
     const uint64_t dist_bytes = octants ? 8 * n_cells : n_cells;
     if ((rc = alloc((void **)&nb.dist, dist_bytes, "distance map"))) return rc;
     nb.vol_bytes = n_cells * cell_bytes + dist_bytes;
@@ -1127,14 +1127,15 @@ static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_
     } else {
         // Skipping costs a distance lookup per probing trip; it only pays when there is something to skip
         // (tools/skip_crossover.py, DESIGN.md section 4: on 256^3 volumes with a share e of exactly-transparent cells
-        // the skip kernel overtakes the dense one between e = 0.36 and e = 0.56).  Default policy by the census taken
-        // at upload:  e < 0.30: the dense kernel;  0.30 <= e < 0.70: the skip kernel with adaptive probing (dense
-        // stretches where nothing is being skipped);  e >= 0.70: the skip kernel probing on every trip (mostly
-        // empty volumes -- the bonsai stand-in is at 0.77 -- spend their time in the skip walks, and the stretches only cost).
+        // the skip kernel overtakes the dense one between e = 0.36 and e = 0.56: 0.335 / 0.348 / 0.407 ms for dense /
+        // adaptive / probing always at e = 0.36, 0.332 / 0.302 / 0.292 at e = 0.56).  Default policy by the census taken
+        // at upload:  e < 0.45: the dense kernel;  0.45 <= e < 0.55: the skip kernel with adaptive probing (dense
+        // stretches where nothing is being skipped);  e >= 0.55: the skip kernel probing on every trip (emptier
+        // volumes -- the bonsai stand-in is at 0.77 -- spend their time in the skip walks, and the stretches only cost).
         // VK_RENDER_FORCE_SKIP takes the skip kernel whatever the census, adaptive unless VK_RENDER_PROBE_ALWAYS.
         const bool forced = (flags & VK_RENDER_FORCE_SKIP) != 0;
-        const bool skip = !(flags & VK_RENDER_NO_SKIP) && (forced || ctx->empty_fraction >= 0.30);
-        if (skip && !forced && ctx->empty_fraction >= 0.70) L.debug_flags &= ~4u;
+        const bool skip = !(flags & VK_RENDER_NO_SKIP) && (forced || ctx->empty_fraction >= 0.45);
+        if (skip && !forced && ctx->empty_fraction >= 0.55) L.debug_flags &= ~4u;
         if (skip && ctx->empty_fraction < 0.05) L.debug_flags |= 8u;  // forced on (almost) solid material: long dense stretches from the start
         // SAFE=false (no per-axis clamps, 32-bit offsets, index tables in LDS) only when provably
         // harmless: the cell array is < 4 GiB, the tables fit a modest LDS budget, and the camera is
