@@ -104,6 +104,37 @@ def test_skip_is_exact(V, O):
     assert ma < mb == rb  # without skipping every iteration fetches taps
 
 
+def test_paced_walks_are_exact(V, O):
+    """A walk may stop anywhere: what is not skipped now is probed again.  Whatever the caps on a walk's length (in a trip in
+    which other lanes sample / in which every lane walks; 0 = none), the frame, the per-pixel iteration counts and the
+    number of sampled steps stay what they are -- on the stand-in and on a half-empty volume, u8 and f16, fast and SAFE."""
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 16 / 9).get_proj_view_matrix()
+    W, H = 640, 360
+    half = _holes_volume(96, 0.5, seed=11)
+    for vol, fl in ((O.volume_standin_u8(128), 0), (half, 0), (half, V.RENDER_SAFE), (half.astype(np.float16) / np.float16(255), 0)):
+        ref, rsteps, _ = O.render(cam, vol, W, H, dt_scale=0.5)
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture(ctx, vol)
+            ctx.set_camera_blob(cam)
+            first = None
+            for cap, cap_all in ((8, 12), (0, 0), (1, 1), (3, 5), (8, 0), (0, 4), (200, 200)):
+                ctx.set_param("walk_cap", cap); ctx.set_param("walk_cap_all", cap_all)
+                for policy in (V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS, V.RENDER_FORCE_SKIP):
+                    ctx.reset_step_counts()
+                    V.RaycastPipeline(dt_scale=0.5, flags=fl | policy | V.RENDER_COUNT).record(ctx)
+                    img, steps, counts = ctx.read_backbuffer(), ctx.read_steps(), ctx.step_counts()
+                    assert (steps == rsteps).all() and counts[0] == int(rsteps.sum()), (cap, cap_all, policy)
+                    if first is None:
+                        first = (img, counts)
+                        assert np.abs(img - ref).max() <= TOL
+                    assert (img.view(np.uint32) == first[0].view(np.uint32)).all(), (cap, cap_all, policy)
+                    if policy & V.RENDER_PROBE_ALWAYS:
+                        assert counts[1] == first[1][1]  # exactly the steps that can contribute, however the walks were cut
+        finally:
+            ctx.close()
+
+
 def _holes_volume(n, p_empty, seed=3, block=16):
     """u8 fog 26..40 (every cell contributes) with 16^3 blocks knocked out to value 10 (exactly transparent) with
     probability p_empty: the share of skippable cells is close to p_empty."""
