@@ -288,11 +288,24 @@ def main():
 
         # untimed counting launch: the units one frame processes
         s_ref, s_sampled = count_steps(ctx, V, flags)
+        # C2 is quoted on one camera.  The beyond-cache configurations march consecutive frames of an orbit instead (yaw step
+        # 2 pi / 1024): identical frames in one launch share their brick fetches in L2 / Infinity Cache and read up to 20 %
+        # faster than any real frame stream (tools/big_batch_orbit.py).  The step counts are then the mean over those frames.
+        cam_list = [blob] * batch
+        if args.config != "c2":
+            cam_list = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
+            tot_ref = tot_samp = 0
+            for cb in cam_list:
+                ctx.set_camera_blob(cb)
+                a, b = count_steps(ctx, V, flags)
+                tot_ref += a; tot_samp += b
+            ctx.set_camera_blob(blob)
+            s_ref, s_sampled = tot_ref // batch, tot_samp // batch
 
         launch_ev = []  # (start, end) HIP events around every batch launch of the timed region
         if not use_dist:
             frames = torch.empty((batch, H, W, 4), dtype=torch.float16, device="cuda")
-            cams = [blob] * batch
+            cams = cam_list
             pending = [0]
 
             def submit(timed):
@@ -333,8 +346,10 @@ def main():
                 transport = "torch"
                 btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport, via_host=rehearsal)
 
+            btr_i = [0]
+
             def submit(timed):
-                btr.submit(blob)
+                btr.submit(cam_list[btr_i[0] % batch]); btr_i[0] += 1
 
             def flush(timed=False):
                 btr.flush()
@@ -413,6 +428,7 @@ def main():
                     "partition": "one launch per batch of whole frames" if not use_dist else
                                  f"{TILE}x{TILE} tiles dealt heaviest-first over {world} ranks, one launch + one RCCL gather (second stream) + one un-tile per batch of {batch} frames",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
+                    **({"cameras": "consecutive frames of an orbit, yaw step 2pi/1024 (step counts: mean over the launch's frames)"} if args.config != "c2" else {}),
                     **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
                 **({"rehearsal": "all ranks on ONE GPU over gloo: a test of the N > 1 flow, not a measurement"} if rehearsal else {}),
