@@ -54,6 +54,16 @@ def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None
         ctx.close()
 
 
+def _synced(t):
+    """A tensor torch has just filled on ITS current stream, handed to the library, which writes on a non-blocking stream of
+    its own: without a synchronisation nothing orders the fill before the library's kernels (torch's streams and the
+    context's do not synchronise with the legacy default stream)."""
+    import torch
+
+    torch.cuda.synchronize()
+    return t
+
+
 def layouts(V):
     return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED, "Q": V.LAYOUT_QUADS,
             "S8": V.LAYOUT_STAGED}
@@ -256,7 +266,7 @@ def test_partition_untile_equals_frame(V, O):
             V.VolumeTexture(ctx, vol)
             ctx.set_camera_blob(cam)
             slots = V.partition_slots(W, H, ts, world)
-            gathered = torch.zeros((world, slots, ts, ts, 4), dtype=torch.float32, device="cuda")
+            gathered = _synced(torch.zeros((world, slots, ts, ts, 4), dtype=torch.float32, device="cuda"))
             pipe = V.RaycastPipeline(dt_scale=0.5)
             for r in range(world):
                 pipe.record_partition(ctx, ts, r, world, gathered[r].data_ptr())
@@ -300,7 +310,7 @@ def test_silhouette_cull_never_drops_a_hit_tile(V, O):
             whole = ctx.read_backbuffer()
             for ts in (16, 32):
                 slots = V.partition_slots(W, H, ts, 1)
-                gathered = torch.full((1, slots, ts, ts, 4), float("nan"), dtype=torch.float32, device="cuda")
+                gathered = _synced(torch.full((1, slots, ts, ts, 4), float("nan"), dtype=torch.float32, device="cuda"))
                 pipe.record_partition(ctx, ts, 0, 1, gathered.data_ptr())
                 n_active, _ = ctx.partition_active(ts, 1)
                 V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, 1, slots))
@@ -343,7 +353,7 @@ def test_render_batch_equals_single_frames(V, O):
                 pipe.record(ctx)
                 singles.append(ctx.read_backbuffer().copy())
             B = len(cc)
-            frames = torch.zeros((B, H, W, 4), dtype=tdt, device="cuda")
+            frames = _synced(torch.zeros((B, H, W, 4), dtype=tdt, device="cuda"))
             V.render_batch(ctx, pipe, cc, frames.data_ptr(), tile_size=ts)
             ctx.sync()
             got = frames.cpu().numpy()
@@ -354,10 +364,10 @@ def test_render_batch_equals_single_frames(V, O):
                 cap = V.partition_slots(W, H, ts, nr, k)
                 gathered = None
                 for r in range(nr):
-                    buf = torch.zeros((cap, B, ts, ts, 4), dtype=tdt, device="cuda")
+                    buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=tdt, device="cuda"))
                     bid, act = V.render_batch(ctx, pipe, cc, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
                     if gathered is None:
-                        gathered = torch.zeros((nr, act, B, ts, ts, 4), dtype=tdt, device="cuda")
+                        gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=tdt, device="cuda"))
                     ctx.sync()
                     gathered[r] = buf[:act]  # what the rank would send: a contiguous prefix
                 frames.zero_()
@@ -382,7 +392,7 @@ def test_render_batch_equals_single_frames(V, O):
                 ctx.set_camera_blob(c)
                 pipe.record(ctx)
                 singles.append(ctx.read_backbuffer().copy())
-            frames = torch.zeros((len(xcams), H, W, 4), dtype=torch.float32, device="cuda")
+            frames = _synced(torch.zeros((len(xcams), H, W, 4), dtype=torch.float32, device="cuda"))
             V.render_batch(ctx, pipe, xcams, frames.data_ptr(), tile_size=ts)
             ctx.sync()
             got = frames.cpu().numpy()
@@ -394,7 +404,7 @@ def test_render_batch_equals_single_frames(V, O):
     ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
     try:
         V.VolumeTexture(ctx, O.volume_fog_u8(16))
-        buf = torch.zeros((4, 64, 64, 4), device="cuda")
+        buf = _synced(torch.zeros((4, 64, 64, 4), device="cuda"))
         cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
         with pytest.raises(V.VokselisError):
             V.render_batch(ctx, V.RaycastPipeline(flags=V.RENDER_COUNT), [cam], buf.data_ptr())
@@ -435,7 +445,7 @@ def test_c2_full_size_batch_and_eight_way_partition(V, O):
         _, rsteps, _ = O.render(cams[0], O.volume_standin_u8(256), W, H, dt_scale=0.5, tile=(640, 300, 640, 64))
         assert (steps[300:364, 640:1280] == rsteps[300:364, 640:1280]).all()
         B = len(cams)
-        frames = torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda")
+        frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda"))
         V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=ts)
         ctx.sync()
         got = frames.cpu().numpy().view(np.uint16)
@@ -446,10 +456,10 @@ def test_c2_full_size_batch_and_eight_way_partition(V, O):
         cap = V.partition_slots(W, H, ts, nr, k)
         gathered = None
         for r in range(nr):
-            buf = torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda")
+            buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
             bid, act = V.render_batch(ctx, pipe, cams, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
             if gathered is None:
-                gathered = torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda")
+                gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
             ctx.sync()
             gathered[r] = buf[:act]
         frames.zero_()
@@ -1281,7 +1291,7 @@ def test_procedural_partition(V, O):
         order = ctx.partition_order(ts, V.MODE_PROCEDURAL)
         assert sorted(order.tolist()) == list(range(15))
         cap = V.partition_slots(W, H, ts, 2)
-        gathered = torch.zeros((2, cap, ts, ts, 4), device="cuda")
+        gathered = _synced(torch.zeros((2, cap, ts, ts, 4), device="cuda"))
         for r in range(2):
             pipe.record_partition(ctx, ts, r, 2, gathered[r].data_ptr())
         V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))

@@ -171,11 +171,15 @@ class BatchTileRenderer:
         ctx.set_root_skip(self.root_skip if self.world > 1 else 0)
         self.cap = partition_slots(self.W, self.H, tile_size, self.world, self.root_skip if self.world > 1 else 0)
         shape = (self.cap, self.batch, tile_size, tile_size, 4)
-        self.send = [torch.zeros(shape, dtype=self.dtype, device=self.dev) for _ in range(2)]
-        self.recv = self.frames = None
-        if self.is_root:
-            self.recv = [torch.zeros((self.world * self.cap * self.batch, tile_size, tile_size, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
-            self.frames = [torch.zeros((self.batch, self.H, self.W, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
+        # The buffers are filled (zeroed) on `march_stream`, not on the caller's current stream: torch's streams do not
+        # synchronise with the legacy default stream, and a zero-fill still queued there could land AFTER the first march
+        # has written its tiles (seen once in ~15 runs of the test that drives this class from the default stream).
+        with torch.cuda.stream(self.march_stream):
+            self.send = [torch.zeros(shape, dtype=self.dtype, device=self.dev) for _ in range(2)]
+            self.recv = self.frames = None
+            if self.is_root:
+                self.recv = [torch.zeros((self.world * self.cap * self.batch, tile_size, tile_size, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
+                self.frames = [torch.zeros((self.batch, self.H, self.W, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
         self.marched = [torch.cuda.Event() for _ in range(2)]   # set s: tiles written
         self.moved = [torch.cuda.Event() for _ in range(2)]     # set s: gather done (send[s] free, recv[s] valid)
         self._used = [False, False]
