@@ -83,7 +83,10 @@ enum vk_render_flags {
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */
 int vk_ctx_create(int device_ordinal, vk_ctx **out);
 int vk_ctx_destroy(vk_ctx *ctx);
-/* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own. */
+/* Run on a caller-owned HIP stream (e.g. torch's current stream); NULL = the context's own.
+ * Stream discipline: every call is asynchronous on the context's stream unless it returns host data.  The context's own
+ * stream is non-blocking -- it does NOT synchronise with the legacy default stream -- so device buffers the caller fills
+ * (or reads) on another stream need an event / synchronisation of the caller's making, or a shared stream set here. */
 int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream);
 int vk_ctx_sync(vk_ctx *ctx);
 /* Context::get_info, src/context.rs:183-203 */
