@@ -1,3 +1,4 @@
+"""How many of a frame's 64x64 tiles does a partition march and move (the silhouette cull), C2 camera."""
 import sys; sys.path.insert(0,'/root/repo')
 import vokselis_amd as V
 W,H=1920,1080

@@ -1,3 +1,4 @@
+"""Host cost of a new camera: set camera + heaviest-first tile order + table upload, per estimate-ray count."""
 import sys, os, time, json
 sys.path.insert(0, '/root/repo')
 import vokselis_amd as V
