@@ -1206,6 +1206,8 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.root_skip = nranks > 1 ? ctx->root_skip : 0u;
     const uint64_t slots = deal_rounds((uint32_t)tiles, nranks, L.root_skip);
     L.n_tiles_launch = (uint32_t)tiles;
+    // (PROCEDURAL / COMPUTE_NEAREST: every tile is active; the naive and staged kernels are the ones that test it)
+    L.n_active_tiles = ctx->order_active;
     if (tiles == 0) return VK_OK;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
     const uint64_t n_blocks = slots * per_tile;

@@ -102,6 +102,7 @@ struct LaunchDesc {
     // (the leading active slots of every frame) are one contiguous prefix; full frames are [frame][H][W].
     const FrameDesc *frames;
     uint32_t n_frames;
+    uint32_t n_active_tiles;       // single-frame launches: leading positions of the order that are active (FrameDesc::pad[0] in batches)
     float walk_cap;                // skip kernels: steps a walk may take in a trip in which other lanes sample (+inf: no cap)
     float walk_cap_all;            // ... and in a trip in which every lane walks
 };
@@ -165,6 +166,7 @@ struct PixelMap {
     int32_t x, y;      // image coordinates
     bool valid;        // inside region and image
     size_t out_index;  // pixel index into the output
+    uint32_t pos;      // position of the wave's tile in the heaviest-first order (wave-uniform)
 };
 
 // The frame a wave belongs to: camera, cull rectangle, order table.  Wave-uniform (scalar loads).
@@ -174,6 +176,7 @@ struct FrameView {
     int32_t cull_x0, cull_y0, cull_x1, cull_y1;
     const uint32_t *order;
     uint32_t n_tiles_launch;
+    uint32_t n_active;  // leading positions whose tiles the box's silhouette can reach; the tiles behind them hold only clear colour
     uint32_t frame;
     uint32_t lb;  // the wave's logical block inside its frame
 };
@@ -194,6 +197,7 @@ __device__ __forceinline__ FrameView frame_view(const LaunchDesc &L, uint32_t lb
         f.cull_x0 = d.cull_x0; f.cull_y0 = d.cull_y0; f.cull_x1 = d.cull_x1; f.cull_y1 = d.cull_y1;
         f.order = L.tile_order + d.order_off;
         f.n_tiles_launch = d.n_active;
+        f.n_active = d.pad[0];
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++) f.eye[i] = L.eye[i];
@@ -202,6 +206,7 @@ __device__ __forceinline__ FrameView frame_view(const LaunchDesc &L, uint32_t lb
         f.cull_x0 = L.cull_x0; f.cull_y0 = L.cull_y0; f.cull_x1 = L.cull_x1; f.cull_y1 = L.cull_y1;
         f.order = L.tile_order;
         f.n_tiles_launch = L.n_tiles_launch;
+        f.n_active = L.n_active_tiles;
         f.frame = 0;
         f.lb = lb;
     }
@@ -226,6 +231,7 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameVi
     m.valid = (tile < n_tiles) && rx < L.rw && ry < L.rh && m.x >= 0 && m.y >= 0 &&
               m.x < (int32_t)L.W && m.y < (int32_t)L.H;
     const uint32_t nf = L.frames ? L.n_frames : 1u;
+    m.pos = pos;
     m.out_index = L.compact ? (((size_t)slot * nf + fv.frame) * L.ts + ly) * L.ts + lx
                             : ((size_t)fv.frame * L.H + (size_t)m.y) * L.W + (size_t)m.x;
     return m;
@@ -882,7 +888,9 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         // Screen-space cull (wave-uniform): an 8x8 block wholly outside the projected cube's bounding
         // rectangle (host-computed, padded) holds only misses: clear colour, no ray set-up.
         const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
-        if (bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {
+        // ... and so does every block of a tile the box's silhouette cannot reach (the inactive tiles behind the order's
+        // active positions: a whole-frame launch covers them too, a partition never launches them)
+        if (pm.pos >= fv.n_active || bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {
             if (!pm.valid) return;
             store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
