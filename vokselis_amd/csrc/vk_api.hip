@@ -1414,7 +1414,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     FrameDesc *fd = reinterpret_cast<FrameDesc *>(B.h);
     uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
     uint32_t *h_pos = h_order + (size_t)n_frames * n_tiles;
-    uint32_t max_active = 0;
+    uint32_t max_active = 0, min_active = 0xffffffffu;
     // The tile order depends on the camera (and the frame / volume shape).  It is written straight into the pinned
     // staging block; a frame with the camera of the frame before it (or of the last frame of the previous batch) copies
     // that frame's tables instead of casting the estimate rays again.
@@ -1452,10 +1452,11 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         cull_rect_cam(ctx, c, geo_mode, cr);
         fd[f].cull_x0 = cr[0]; fd[f].cull_y0 = cr[1]; fd[f].cull_x1 = cr[2]; fd[f].cull_y1 = cr[3];
         fd[f].order_off = (uint32_t)(f * n_tiles);
-        // whole frames cover every tile (the kernel clears the inactive ones); a rank's share only the active ones
-        fd[f].n_active = compact ? n_active : (uint32_t)n_tiles;
+        // the march covers the active tiles only; whole frames get their inactive ones from clear_inactive_tiles_kernel
+        fd[f].n_active = n_active;
         fd[f].pad[0] = n_active; fd[f].pad[1] = 0;
         max_active = std::max(max_active, n_active);
+        min_active = std::min(min_active, n_active);
     }
     {   // remember the last frame's tables for the next batch
         const uint32_t l = n_frames - 1;
@@ -1468,12 +1469,24 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     const uint32_t root_skip = nranks > 1 ? ctx->root_skip : 0u;
     const uint32_t slots_active = deal_rounds(max_active, nranks, root_skip);
     if (n_active_slots) *n_active_slots = slots_active;
-    const uint64_t slots = compact ? (uint64_t)slots_active : (uint64_t)n_tiles;
+    const uint64_t slots = (uint64_t)slots_active;  // (whole frames: nranks == 1, so slots_active == max_active)
     if (compact && slots_active > slot_capacity) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: slot_capacity smaller than the active slots of this batch");
     HIP_TRY(ctx, hipMemcpyAsync(B.d, B.h, bytes, hipMemcpyHostToDevice, ctx->stream));
     B.id = ++ctx->batch_seq;
     B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active; B.root_skip = root_skip;
     if (batch_id) *batch_id = B.id;
+    if (!compact && min_active < n_tiles) {
+        const uint32_t max_inactive = (uint32_t)n_tiles - min_active, chunks = (ts * ts + 511u) / 512u;
+        const uint64_t blocks = (uint64_t)n_frames * max_inactive * chunks;
+        if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large: fewer frames per batch");
+        const FrameDesc *dfr = reinterpret_cast<const FrameDesc *>(B.d);
+        const uint32_t *dord = reinterpret_cast<const uint32_t *>(B.d + (size_t)n_frames * sizeof(FrameDesc));
+        if (ctx->out_format == VK_OUT_RGBA16F)
+            hipLaunchKernelGGL(clear_inactive_tiles_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, out, ctx->width, ctx->height, ts, tx, (uint32_t)n_tiles, n_frames, max_inactive, dord, dfr);
+        else
+            hipLaunchKernelGGL(clear_inactive_tiles_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, out, ctx->width, ctx->height, ts, tx, (uint32_t)n_tiles, n_frames, max_inactive, dord, dfr);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (slots == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
     LaunchDesc L{};
     L.W = ctx->width; L.H = ctx->height;

@@ -1728,4 +1728,32 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
     }
 }
 
+// Whole frames in a batched launch: the tiles behind a frame's active positions hold only the clear colour
+// (examples/bonsai/main.rs:41).  The march launch no longer covers them -- 20 000 waves per C2 frame whose only work was a
+// store behind the full set-up of a march wave -- and this kernel writes them: one workgroup clears 512 pixels of one
+// inactive tile, two adjacent pixels (16 / 32 bytes) per lane.  order: per frame, position -> tile id.
+template <int OUT>
+__global__ __launch_bounds__(256) void clear_inactive_tiles_kernel(void *__restrict__ out, uint32_t W, uint32_t H, uint32_t ts, uint32_t tiles_x, uint32_t n_tiles,
+                                                                   uint32_t n_frames, uint32_t max_inactive, const uint32_t *__restrict__ order,
+                                                                   const FrameDesc *__restrict__ frames) {
+    const uint32_t chunks = (ts * ts + 511u) / 512u;
+    uint32_t b = blockIdx.x;
+    const uint32_t chunk = b % chunks; b /= chunks;
+    const uint32_t j = b % max_inactive;
+    const uint32_t frame = b / max_inactive;
+    if (frame >= n_frames) return;
+    const uint32_t pos = frames[frame].pad[0] + j;  // pad[0]: the frame's active tile count
+    if (pos >= n_tiles) return;
+    const uint32_t tile = order[(size_t)frame * n_tiles + pos];
+    const uint32_t l = chunk * 512u + threadIdx.x * 2u;
+    if (l >= ts * ts) return;
+    const uint32_t ly = l / ts, lx = l - ly * ts;
+    const uint32_t tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const uint32_t x = txi * ts + lx, y = tyi * ts + ly;
+    if (x >= W || y >= H) return;
+    const size_t dst = ((size_t)frame * H + y) * W + x;
+    store_pixel<OUT>(out, dst, 0.0f, 0.0f, 0.0f, 1.0f);
+    if (x + 1u < W) store_pixel<OUT>(out, dst + 1, 0.0f, 0.0f, 0.0f, 1.0f);
+}
+
 }  // namespace vk
