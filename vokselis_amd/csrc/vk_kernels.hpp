@@ -645,6 +645,19 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
         float r = fmaf(fz, c1 - c0, c0);
         const float a = transfer_alpha<(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) ? 1 : 0>(r);
+        if (SKIP) {
+            // A cell is non-empty as soon as one of its 8 taps is above the threshold; the FILTERED value of a sample inside it
+            // often is not (a lone voxel just above it, a silhouette), and then alpha is exactly 0: w = 0, every accumulator
+            // takes +0 (the cosines are finite).  When that holds for every lane sampling in this trip -- it mostly does in
+            // the executions that serve one or two lanes -- the palette and the compositing are left out: 17 of the 45
+            // instructions, no bit changes.
+            if (__ballot(a != 0.0f) == 0ull) {
+                if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
+                px = px + sx; py = py + sy; pz = pz + sz;  // :118
+                t = t + dt;
+                continue;
+            }
+        }
         // vertigo(): cos(6.28318*(c*a + d)); v_cos_f32 takes revolutions
         constexpr double kk = 6.28318 / 6.283185307179586476925;
         constexpr float pc0 = (float)(1.0 * kk), pc1 = (float)(1.7 * kk), pc2 = (float)(0.4 * kk);
