@@ -34,7 +34,7 @@ for name, mk, fl in cases:
     mk(); ctx.update()
     pipe = V.RaycastPipeline(dt_scale=0.5, flags=fl)
     ref = None
-    for cap, cap_all in ((0, 0), (8, 0), (8, 12), (8, 16), (8, 20), (8, 24), (8, 32), (8, 0)):
+    for cap, cap_all in ((8, 12), (0, 0), (4, 12), (8, 8), (8, 16), (12, 12), (12, 16), (16, 16), (8, 12)):
         ctx.set_param("walk_cap", cap); ctx.set_param("walk_cap_all", cap_all)
         for _ in range(400): pipe.record(ctx)   # clocks: ~60 ms
         single = t(lambda: pipe.record(ctx), 50)
