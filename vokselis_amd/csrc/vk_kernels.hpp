@@ -547,8 +547,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
             // 3.9 iterations of four steps per trip with 19 of 64 lanes active).  In such a trip walks are capped; the walker
             // probes again next trip, which the wave makes anyway.  Any stop is exact: what is not skipped now is probed again.
             // (One compare serves the branch and the wave-level test; the cap is a scalar.)
-            const unsigned long long walkers = SKIP ? __ballot(d != 0) : 0ull;
-            const float cap_now = (walkers != __ballot(true)) ? walk_cap : walk_cap_all;
+            // (one compare serves the branch and the wave-level test; the cap is chosen on the scalar unit, as bits)
+            const unsigned long long samplers = SKIP ? __ballot(d == 0) : 0ull;
+            const uint32_t cap_now = samplers != 0ull ? __builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap)) : __builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap_all));
             if (SKIP && d != 0) {
                 if (BOUNDED) cs.skips++;
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
@@ -565,7 +566,8 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
                 float rmin = fminf(fminf(rx, ry), rz);
                 asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
-                const float tstop = fminf(fmaf(rmin, dt, t), t1q);
+                float tstop = fmaf(rmin, dt, t);
+                asm("v_min_f32 %0, %1, %2" : "=v"(tstop) : "v"(tstop), "v"(t1q));    // (t1 is finite: no canonicalise per trip)
                 const float tstop2 = fmaf(-1.5f, dt, tstop);  // t < tstop2  =>  t + dt < tstop as well
                 const float tstop4 = fmaf(-3.5f, dt, tstop);  // t < tstop4  =>  t + 3 dt < tstop as well
                 px = px + sx; py = py + sy; pz = pz + sz;
