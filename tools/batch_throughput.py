@@ -39,9 +39,11 @@ for B in (16, 32):
                 per_rank.append(timeit(lambda: V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=r, nranks=nr, compact=True, slot_capacity=capk)))
             bid, act = V.render_batch(ctx, pipe, [blob] * B, buf.data_ptr(), tile_size=TS, rank=0, nranks=nr, compact=True, slot_capacity=capk)
             g2 = gathered[:, :act].contiguous()
-            un = timeit(lambda: V.untile_batch(ctx, bid, g2.data_ptr(), act, frames.data_ptr()))
+            un_full = timeit(lambda: V.untile_batch(ctx, bid, g2.data_ptr(), act, frames.data_ptr()))
+            # as the driver calls it: the frame buffer still holds the un-tile of the batch before last (a still camera here)
+            un = timeit(lambda: V.untile_batch(ctx, bid, g2.data_ptr(), act, frames.data_ptr(), prev_batch_id=bid))
             root = per_rank[0] + un
-            print(json.dumps({"batch": B, "nranks": nr, "root_skip": k, "root_march+untile_us_per_frame": round(root / B * 1e3, 1), "untile_us_per_frame": round(un / B * 1e3, 1),
+            print(json.dumps({"batch": B, "nranks": nr, "root_skip": k, "root_march+untile_us_per_frame": round(root / B * 1e3, 1), "untile_us_per_frame": round(un / B * 1e3, 1), "untile_full_us_per_frame": round(un_full / B * 1e3, 1),
                               "slowest_peer_us_per_frame": round(max(per_rank[1:] or [0]) / B * 1e3, 1), "bound_us_per_frame": round(max(root, max(per_rank)) / B * 1e3, 1)}))
 ctx.set_root_skip(0)
 ctx.close()

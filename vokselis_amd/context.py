@@ -363,8 +363,10 @@ def render_batch(ctx: Context, pipe: RaycastPipeline, cameras, out_ptr: int, *, 
     return bid.value, act.value
 
 
-def untile_batch(ctx: Context, batch_id: int, gathered_ptr: int, n_slots: int, out_ptr: int):
-    N.check(ctx.handle, N.lib().vk_untile_batch(ctx.handle, batch_id, C.c_void_p(gathered_ptr), n_slots, C.c_void_p(out_ptr)))
+def untile_batch(ctx: Context, batch_id: int, gathered_ptr: int, n_slots: int, out_ptr: int, prev_batch_id: int = 0):
+    """vk_untile_batch / vk_untile_batch_over: `prev_batch_id` names the batch whose un-tiled frames `out_ptr` still holds,
+    untouched (0: unknown -- every inactive tile is cleared)."""
+    N.check(ctx.handle, N.lib().vk_untile_batch_over(ctx.handle, batch_id, C.c_void_p(gathered_ptr), n_slots, C.c_void_p(out_ptr), int(prev_batch_id)))
 
 
 def partition_slots(width: int, height: int, tile_size: int, nranks: int, root_skip: int = 0) -> int:

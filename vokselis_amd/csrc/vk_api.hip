@@ -1513,10 +1513,19 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
 }
 
 int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32_t n_slots, void *out_frames) {
+    return vk_untile_batch_over(ctx, batch_id, gathered, n_slots, out_frames, 0u);
+}
+
+int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32_t n_slots, void *out_frames, uint32_t prev_batch_id) {
     if (!ctx || !gathered || !out_frames) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: NULL argument");
-    vk_ctx::BatchSlot *B = nullptr;
+    vk_ctx::BatchSlot *B = nullptr, *P = nullptr;
     for (auto &b : ctx->batch) if (b.id == batch_id && b.id != 0) B = &b;
     if (!B) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: that batch is no longer held (more than 3 batches ago)");
+    // out_frames still holds the result of un-tiling `prev_batch_id` (the caller's word): tiles inactive then and now are not
+    // written again.  A batch of another shape, or one no longer held, is simply not used.
+    if (prev_batch_id != 0)
+        for (auto &b : ctx->batch) if (b.id == prev_batch_id) P = &b;
+    if (P && (P->n_frames != B->n_frames || P->n_tiles != B->n_tiles || P->ts != B->ts || !P->d)) P = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t tx = (ctx->width + B->ts - 1) / B->ts;
     const uint32_t chunks = (B->ts * B->ts + 511u) / 512u;
@@ -1525,12 +1534,15 @@ int vk_untile_batch(vk_ctx *ctx, uint32_t batch_id, const void *gathered, uint32
     const FrameDesc *frames = reinterpret_cast<const FrameDesc *>(B->d);
     const uint32_t *pos = reinterpret_cast<const uint32_t *>(B->d + (size_t)B->n_frames * sizeof(FrameDesc)) + (size_t)B->n_frames * B->n_tiles;
     // FrameDesc::n_active of a compact batch is the frame's active tile count (what the gather carried)
+    const FrameDesc *pframes = P ? reinterpret_cast<const FrameDesc *>(P->d) : nullptr;
+    const uint32_t *ppos = P ? reinterpret_cast<const uint32_t *>(P->d + (size_t)P->n_frames * sizeof(FrameDesc)) + (size_t)P->n_frames * P->n_tiles : nullptr;
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes);
     else
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(B->ev, ctx->stream));
+    if (P) HIP_TRY(ctx, hipEventRecord(P->ev, ctx->stream));  // (its tables were read too: the slot is reused after this launch)
     return VK_OK;
 }
 

@@ -1701,7 +1701,8 @@ template <int OUT>
 __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restrict__ gathered, void *__restrict__ out, uint32_t W, uint32_t H, uint32_t ts,
                                                            uint32_t tiles_x, uint32_t n_tiles, uint32_t nranks, uint32_t n_slots, uint32_t n_frames,
                                                            const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames, uint32_t root_skip,
-                                                           uint32_t n_active_one) {
+                                                           uint32_t n_active_one, const uint32_t *__restrict__ prev_tile_pos = nullptr,
+                                                           const FrameDesc *__restrict__ prev_frames = nullptr) {
     const uint32_t chunks = (ts * ts + 511u) / 512u;  // 512-pixel chunks per tile
     uint32_t b = blockIdx.x;
     const uint32_t chunk = b % chunks; b /= chunks;
@@ -1718,7 +1719,9 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
     const size_t dst = ((size_t)frame * H + y) * W + x;
     const uint32_t pos = tile_pos[(size_t)frame * n_tiles + tile];
     const uint32_t n_active = frames ? frames[frame].n_active : n_active_one;
-    if (pos >= n_active) {  // outside the cube's screen rectangle: never marched, never gathered
+    if (pos >= n_active) {  // the box's silhouette cannot reach this tile: never marched, never gathered
+        // `out` still holds the un-tiled frames of an earlier batch (prev_*): a tile that was inactive then as well is clear already
+        if (prev_tile_pos && prev_tile_pos[(size_t)frame * n_tiles + tile] >= prev_frames[frame].n_active) return;
         store_pixel<OUT>(out, dst, 0.0f, 0.0f, 0.0f, 1.0f);
         if (two) store_pixel<OUT>(out, dst + 1, 0.0f, 0.0f, 0.0f, 1.0f);
         return;

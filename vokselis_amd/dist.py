@@ -115,7 +115,8 @@ class BatchTileRenderer:
 
     submit(camera_blob) queues a frame; a full batch is launched at once.  On the root, finished batches arrive in
     `on_batch(first_frame_index, count, frames)` with frames a [count, H, W, 4] cuda tensor view (valid until the
-    next-but-one batch is launched).  flush() launches a partial batch and drains."""
+    next-but-one batch is launched; READ-ONLY: the next un-tile into that buffer relies on what this one left there and
+    rewrites only the tiles whose state changed).  flush() launches a partial batch and drains."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, batch: int = 16, root: int = 0, group=None,
                  transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto"):
@@ -183,6 +184,7 @@ class BatchTileRenderer:
         self.marched = [torch.cuda.Event() for _ in range(2)]   # set s: tiles written
         self.moved = [torch.cuda.Event() for _ in range(2)]     # set s: gather done (send[s] free, recv[s] valid)
         self._used = [False, False]
+        self._frames_bid = [0, 0]  # the batch last un-tiled into frames[s] (0: none yet -- the buffer holds zeros, not the clear colour)
         self._cams, self._set = [], 0
         self._pending = None  # (set, batch id, active slots, count, first index)
         self._submitted = 0
@@ -274,7 +276,9 @@ class BatchTileRenderer:
         if not self.is_root:
             return
         self.march_stream.wait_event(self.moved[s])
-        untile_batch(self.ctx, bid, self.recv[s].data_ptr(), act, self.frames[s].data_ptr())
+        # frames[s] still holds what this object un-tiled into it two batches ago: only tiles whose state changed are cleared
+        untile_batch(self.ctx, bid, self.recv[s].data_ptr(), act, self.frames[s].data_ptr(), prev_batch_id=self._frames_bid[s])
+        self._frames_bid[s] = bid
         if self.on_batch is not None:
             self.on_batch(first, count, self.frames[s][:count])
 
