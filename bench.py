@@ -236,6 +236,11 @@ def main():
     cfg = CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
     batch = args.batch or {"c2": 32, "c4": 4, "c5": 2}[args.config]
+    if not args.batch and args.config == "c2" and world > 1:
+        # a rank's launch covers 1 / N of every frame: as many more frames keep it as long as the one-GPU launch, whose tail it
+        # would otherwise pay N times as often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at
+        # 16 / 32 / 64 / 128 frames per launch)
+        batch = min(256, 16 * world)
     batch = max(1, min(batch, args.steps))
     if not args.batch:
         # K frames in ceil(K / batch) launches of (almost) equal size: a padded last launch would march frames nobody counts
