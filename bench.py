@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE config to run (the metric is quoted on c2)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 64 for c2 -- 16 per rank at N > 1 --, 4 for c4, 2 for c5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 64 for c2, times N up to 256 at N > 1,, 4 for c4, 2 for c5)")
     ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
     ap.add_argument("--layout", default="auto", choices=["auto", "pairs", "packed", "bricked", "staged"], help="volume layout (auto: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,7 +240,7 @@ def main():
         # a rank's launch covers 1 / N of every frame: as many more frames keep it as long as the one-GPU launch, whose tail it
         # would otherwise pay N times as often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at
         # 16 / 32 / 64 / 128 frames per launch)
-        batch = min(256, 16 * world)
+        batch = min(256, 64 * world)  # (256: the most one vk_render_batch spans)
     batch = max(1, min(batch, args.steps))
     if not args.batch:
         # K frames in ceil(K / batch) launches of (almost) equal size: a padded last launch would march frames nobody counts
