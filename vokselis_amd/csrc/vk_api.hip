@@ -1092,7 +1092,14 @@ static int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_
     V.nx = ctx->nx; V.ny = ctx->ny; V.nz = ctx->nz;
     V.nbx = ctx->nbx; V.nby = ctx->nby; V.nbz = ctx->nbz;
     const uint64_t n_blocks = L.n_blocks;
-    const uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
+    uint32_t grid = (uint32_t)((n_blocks + 511) / 512 * 512);
+    L.grid_march = grid;
+    if (mode != VK_MODE_NAIVE_TRILINEAR) L.clear_max_inactive = 0;  // (their kernels have no clearing blocks: every tile is active)
+    // whole-frame batches: the strips that clear the inactive tiles ride behind the march blocks (clear_inactive_strip)
+    const uint64_t clear_blocks = (uint64_t)L.clear_max_inactive * L.n_frames * ((L.ts * L.ts + 511u) / 512u);
+    if ((uint64_t)grid + clear_blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large: fewer frames per batch");
+    grid += (uint32_t)clear_blocks;
+    if (grid == 0) return VK_OK;
     if (mode == VK_MODE_PROCEDURAL) {
         float time = 0.0f;
         std::memcpy(&time, ctx->uniform + 36, sizeof(float));  // Uniform.time (global_ubo.rs:52-65), what xor.wgsl reads as un.time
@@ -1452,7 +1459,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         cull_rect_cam(ctx, c, geo_mode, cr);
         fd[f].cull_x0 = cr[0]; fd[f].cull_y0 = cr[1]; fd[f].cull_x1 = cr[2]; fd[f].cull_y1 = cr[3];
         fd[f].order_off = (uint32_t)(f * n_tiles);
-        // the march covers the active tiles only; whole frames get their inactive ones from clear_inactive_tiles_kernel
+        // the march covers the active tiles only; whole frames get their inactive ones from the clearing strips at the end of the grid
         fd[f].n_active = n_active;
         fd[f].pad[0] = n_active; fd[f].pad[1] = 0;
         max_active = std::max(max_active, n_active);
@@ -1475,20 +1482,11 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     B.id = ++ctx->batch_seq;
     B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active; B.root_skip = root_skip;
     if (batch_id) *batch_id = B.id;
-    if (!compact && min_active < n_tiles) {
-        const uint32_t max_inactive = (uint32_t)n_tiles - min_active, chunks = (ts * ts + 511u) / 512u;
-        const uint64_t blocks = (uint64_t)n_frames * max_inactive * chunks;
-        if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large: fewer frames per batch");
-        const FrameDesc *dfr = reinterpret_cast<const FrameDesc *>(B.d);
-        const uint32_t *dord = reinterpret_cast<const uint32_t *>(B.d + (size_t)n_frames * sizeof(FrameDesc));
-        if (ctx->out_format == VK_OUT_RGBA16F)
-            hipLaunchKernelGGL(clear_inactive_tiles_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, out, ctx->width, ctx->height, ts, tx, (uint32_t)n_tiles, n_frames, max_inactive, dord, dfr);
-        else
-            hipLaunchKernelGGL(clear_inactive_tiles_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, out, ctx->width, ctx->height, ts, tx, (uint32_t)n_tiles, n_frames, max_inactive, dord, dfr);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    if (slots == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
+    // whole frames: the tiles behind a frame's active positions get their clear colour from strips at the end of the grid
+    const uint32_t clear_max_inactive = (!compact && geo_mode == VK_MODE_NAIVE_TRILINEAR && min_active < n_tiles) ? (uint32_t)n_tiles - min_active : 0u;
+    if (slots == 0 && clear_max_inactive == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
     LaunchDesc L{};
+    L.clear_max_inactive = clear_max_inactive;
     L.W = ctx->width; L.H = ctx->height;
     L.ox = 0; L.oy = 0; L.rw = ctx->width; L.rh = ctx->height;
     L.ts = ts; L.tiles_x = tx; L.tiles_y = ty;

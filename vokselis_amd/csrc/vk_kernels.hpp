@@ -103,6 +103,8 @@ struct LaunchDesc {
     const FrameDesc *frames;
     uint32_t n_frames;
     uint32_t n_active_tiles;       // single-frame launches: leading positions of the order that are active (FrameDesc::pad[0] in batches)
+    uint32_t grid_march;           // blocks of the grid that march (a multiple of 512); the blocks behind them clear inactive tiles
+    uint32_t clear_max_inactive;   // ... of whole-frame batches: inactive tiles per frame at most (0: no such blocks)
     float walk_cap;                // skip kernels: steps a walk may take in a trip in which other lanes sample (+inf: no cap)
     float walk_cap_all;            // ... and in a trip in which every lane walks
 };
@@ -889,9 +891,37 @@ __device__ __forceinline__ void march_quads_stream(const VolumeDesc &V, RayState
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
+// Whole frames in a batched launch: the march covers the active tiles; the tiles behind a frame's active positions hold
+// only the clear colour (examples/bonsai/main.rs:41).  They are written by extra blocks at the END of the same grid -- one
+// wave clears 512 pixels, 64 consecutive ones per store -- which the dispatcher hands out when the last march waves are
+// draining: the stores ride in the launch's tail.  (As blocks of the march proper they were 20 000 waves per C2 frame whose
+// only work was a store behind a full wave set-up; as a kernel of their own they cost 2.7 us per frame in series.)
+template <int OUT>
+__device__ __forceinline__ void clear_inactive_strip(const LaunchDesc &L, uint32_t b, uint32_t lane) {
+    const uint32_t strips = (L.ts * L.ts + 511u) / 512u;  // 512-pixel strips per tile
+    const uint32_t strip = b % strips; b /= strips;
+    const uint32_t j = b % L.clear_max_inactive;
+    const uint32_t frame = b / L.clear_max_inactive;
+    if (frame >= L.n_frames) return;
+    const FrameDesc &d = L.frames[frame];
+    const uint32_t n_tiles = L.tiles_x * L.tiles_y, pos = d.pad[0] + j;  // pad[0]: the frame's active tile count
+    if (pos >= n_tiles) return;
+    const uint32_t tile = L.tile_order[d.order_off + pos];
+    const uint32_t tyi = tile / L.tiles_x, txi = tile - tyi * L.tiles_x;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) {  // store k of the wave covers 64 consecutive pixels of the tile's rows
+        const uint32_t l = strip * 512u + k * 64u + lane;
+        if (l >= L.ts * L.ts) return;
+        const uint32_t ly = l / L.ts, lx = l - ly * L.ts;
+        const uint32_t x = txi * L.ts + lx, y = tyi * L.ts + ly;
+        if (x < L.W && y < L.H) store_pixel<OUT>(L.out, ((size_t)frame * L.H + y) * L.W + x, 0.0f, 0.0f, 0.0f, 1.0f);
+    }
+}
+
 template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
+    if (blockIdx.x >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x - L.grid_march, threadIdx.x); return; }  // wave-uniform
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
@@ -1744,34 +1774,6 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
             if (two) o[dst + 1] = g[src + 1];
         }
     }
-}
-
-// Whole frames in a batched launch: the tiles behind a frame's active positions hold only the clear colour
-// (examples/bonsai/main.rs:41).  The march launch no longer covers them -- 20 000 waves per C2 frame whose only work was a
-// store behind the full set-up of a march wave -- and this kernel writes them: one workgroup clears 512 pixels of one
-// inactive tile, two adjacent pixels (16 / 32 bytes) per lane.  order: per frame, position -> tile id.
-template <int OUT>
-__global__ __launch_bounds__(256) void clear_inactive_tiles_kernel(void *__restrict__ out, uint32_t W, uint32_t H, uint32_t ts, uint32_t tiles_x, uint32_t n_tiles,
-                                                                   uint32_t n_frames, uint32_t max_inactive, const uint32_t *__restrict__ order,
-                                                                   const FrameDesc *__restrict__ frames) {
-    const uint32_t chunks = (ts * ts + 511u) / 512u;
-    uint32_t b = blockIdx.x;
-    const uint32_t chunk = b % chunks; b /= chunks;
-    const uint32_t j = b % max_inactive;
-    const uint32_t frame = b / max_inactive;
-    if (frame >= n_frames) return;
-    const uint32_t pos = frames[frame].pad[0] + j;  // pad[0]: the frame's active tile count
-    if (pos >= n_tiles) return;
-    const uint32_t tile = order[(size_t)frame * n_tiles + pos];
-    const uint32_t l = chunk * 512u + threadIdx.x * 2u;
-    if (l >= ts * ts) return;
-    const uint32_t ly = l / ts, lx = l - ly * ts;
-    const uint32_t tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-    const uint32_t x = txi * ts + lx, y = tyi * ts + ly;
-    if (x >= W || y >= H) return;
-    const size_t dst = ((size_t)frame * H + y) * W + x;
-    store_pixel<OUT>(out, dst, 0.0f, 0.0f, 0.0f, 1.0f);
-    if (x + 1u < W) store_pixel<OUT>(out, dst + 1, 0.0f, 0.0f, 0.0f, 1.0f);
 }
 
 }  // namespace vk

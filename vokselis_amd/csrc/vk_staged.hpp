@@ -396,6 +396,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
 template <int VOL, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void raymarch_staged_kernel(const LaunchDesc L, const VolumeDesc V, const StagedDesc D) {
     static_assert(VOL == VOL_S8U8 || VOL == VOL_S8F16, "staged layouts");
+    if (blockIdx.x >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x - L.grid_march, threadIdx.x); return; }  // wave-uniform
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
     const uint32_t lane = threadIdx.x;
