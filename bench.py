@@ -446,8 +446,8 @@ def main():
                 out["roofline"] = {
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": ("vk::raymarch_naive_kernel" if args.config == "c2" and args.layout in ("auto", "pairs", "packed") else "vk::raymarch_staged_kernel")
-                              + " (one vk_render_batch spanning %d frames: the march of the active tiles + vk::clear_inactive_tiles_kernel, which writes the clear colour"
-                                " of the other tiles -- their pixels are part of the algorithmic bytes; both are between the events)" % n_launch_frames,
+                              + " (one launch spanning %d frames: the active tiles are marched, strips at the end of the same grid write the clear"
+                                " colour of the others)" % n_launch_frames,
                     "launch_ms": launch_ms, "frames_per_launch": n_launch_frames, "launches_timed": len(evs),
                     "algorithmic_bytes_per_launch": alg,
                     "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
