@@ -371,6 +371,7 @@ def test_render_batch_equals_single_frames(V, O):
                     ctx.sync()
                     gathered[r] = buf[:act]  # what the rank would send: a contiguous prefix
                 frames.zero_()
+                torch.cuda.synchronize()  # torch's copies and fill (its own stream) before the library reads / writes them
                 V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
                 ctx.sync()
                 got = frames.cpu().numpy()
@@ -463,6 +464,7 @@ def test_c2_full_size_batch_and_eight_way_partition(V, O):
             ctx.sync()
             gathered[r] = buf[:act]
         frames.zero_()
+        torch.cuda.synchronize()  # torch's copies and fill (its own stream) before the library reads / writes them
         V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
         ctx.sync()
         got = frames.cpu().numpy().view(np.uint16)
@@ -1181,6 +1183,27 @@ def test_baseline_configs_full_size(V, O, name, n, f16, W, H, seed, tile):
             if lname == "auto":  # the production (uninstrumented) kernel gives the same frame
                 V.RaycastPipeline(dt_scale=0.5).record(ctx)
                 assert (ctx.read_backbuffer().view(np.uint32) == imgs["auto"].view(np.uint32)).all()
+                # ... and so does the 8-way partition of it (how BASELINE runs C5): every rank's compact launch emulated here,
+                # gathered side by side, un-tiled -- two frames per launch, the second one the same camera again
+                import torch
+
+                nr, ts, B = 8, 64, 2
+                cap = V.partition_slots(W, H, ts, nr)
+                gathered = _synced(torch.zeros((nr, cap, B, ts, ts, 4), dtype=torch.float32, device="cuda"))
+                frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float32, device="cuda"))
+                pipe = V.RaycastPipeline(dt_scale=0.5)
+                for r in range(nr):
+                    bid, act = V.render_batch(ctx, pipe, [cam] * B, gathered[r].data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
+                assert 0 < act <= cap
+                ctx.sync()  # the library's launches (its stream) before torch reads their output ...
+                packed = gathered[:, :act].contiguous()
+                torch.cuda.synchronize()  # ... and torch's copy (its stream) before the library reads it
+                V.untile_batch(ctx, bid, packed.data_ptr(), act, frames.data_ptr())
+                ctx.sync()
+                out = frames.cpu().numpy()
+                for b in range(B):
+                    assert (out[b].view(np.uint32) == imgs["auto"].view(np.uint32)).all(), (name, "partition", b)
+                del gathered, frames, packed
         finally:
             ctx.close()
     for other in ("b9", "lin"):
