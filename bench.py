@@ -189,7 +189,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         gb = alg / (ms * 1e-3) / 1e9
         # the same frames several per launch (vk_render_batch), as the headline is run: a single launch of a few rounds of
         # LDS-limited waves loses its tail
-        nb = 4 if key == "c4" else 2
+        nb = 4
         fr = torch.empty((nb, H, W, 4), dtype=torch.float16, device="cuda")
         # consecutive frames of an orbit (yaw step 2 pi / 1024), not one camera repeated: identical frames in one launch
         # share their brick fetches in L2 / Infinity Cache and run up to 20 % faster than any real frame stream
@@ -235,7 +235,7 @@ def main():
         args.gpus = world
     cfg = CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
-    batch = args.batch or {"c2": 64, "c4": 4, "c5": 2}[args.config]  # (C2 per frame at 32 / 64 / 128 frames per launch: 0.0677 / 0.0659 / 0.0644 ms)
+    batch = args.batch or {"c2": 64, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 frames per launch: 0.0677 / 0.0659 / 0.0644 ms)
     if not args.batch and args.config == "c2" and world > 1:
         # a rank's launch covers 1 / N of every frame: as many more frames keep it as long as the one-GPU launch, whose tail it
         # would otherwise pay N times as often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at
