@@ -5,6 +5,7 @@ fraction of the HBM-read roofline (BASELINE.json / SURVEY.md 8d, config C2).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c5] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(typed without torchrun, `--gpus N` with N > 1 starts its own ranks as a child torch.distributed.run and relays the line)
 
 A "step" is one frame: one pass of the raycast over every pixel.  Frames are submitted `batch` at a time: ONE launch
 spans the batch (vk_render_batch; the reference keeps frames in flight through its queue, src/lib.rs:178-194).
@@ -13,11 +14,15 @@ heaviest-first over the ranks, every rank marches its tiles of the batch in one 
 own communicator, vk_gather_tiles) brings them to rank 0 over xGMI on a second stream while the next batch is
 marched, rank 0 un-tiles (scaling: strong -- the frames are fixed).
 
-value   = S_ref * K / t  [Mray-steps/s]: S_ref = loop iterations the reference shader executes for one frame (with its
-          alpha >= 0.95 early-out), counted by the kernel itself in an untimed counting launch and equal to the
-          oracle's count (tests).  Volume resident in HBM.  The timed region of exactly K frames is repeated (3 times;
-          more while K < 100, up to 10) and the median repetition reported (`repeats`, `repeat_ms_per_step` in run
+value   = S_ref * M / t  [Mray-steps/s]: S_ref = loop iterations the reference shader executes for one frame (with its
+          alpha >= 0.95 early-out), counted by the kernel itself in untimed counting launches (the mean over the
+          launch's cameras) and equal to the oracle's count (tests).  Volume resident in HBM.  ONE contiguous timed
+          window of M >= max(100, 4 launches) frames, M a multiple of K (SURVEY 8d asks for >= 100 timed frames, and a
+          gather pipeline only fills over several launches): `timed_frames`, `launches_per_region`; the same rule at
+          every N.  The window is repeated 3 times and the median reported (`repeats`, `repeat_ms_per_step` in run
           order); an untimed pre-roll of the same path brings the GPU to its sustained clocks first (`preroll_frames`).
+          The frames of a launch are consecutive frames of an orbit around the config's camera (yaw step 2 pi / 1024),
+          every frame its own camera; the same launch with ONE camera repeated is reported beside it (`still_camera`).
 roofline: algorithmic bytes of one launch = batch * (S_sampled * B_step + W*H * 8 B), B_step = 8 B (8 u8 taps) or 16 B
           (f16), over the launch's mean duration from HIP events on the launch stream, against 8 TB/s.
           See DESIGN.md "Measurement".
@@ -65,7 +70,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE config to run (the metric is quoted on c2)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 64 for c2, times N up to 256 at N > 1,, 4 for c4, 2 for c5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 64 for c2 -- 32 N at N > 1, at most 256 --, 4 for c4 and c5)")
     ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
     ap.add_argument("--layout", default="auto", choices=["auto", "pairs", "packed", "bricked", "staged"], help="volume layout (auto: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,8 +223,43 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ctx.close()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed like the N = 1 line: start the N ranks as a CHILD torch.distributed.run (never an exec,
+    and before anything in this process has touched the GPU), relay its output, leave with its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        import torch
+        n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    except Exception:
+        n_dev = 0
+    if 0 < n_dev < args.gpus and env.get("VK_BENCH_REHEARSAL", "") != "1":
+        if args.gpus > 6:
+            sys.exit("bench.py --gpus %d: this box has %d GPU(s) and a rehearsal on one GPU takes at most 6 ranks" % (args.gpus, n_dev))
+        print("[bench] %d GPU(s) visible for --gpus %d: REHEARSAL (every rank on GPU 0, tiles over gloo) -- a test of the flow, not a measurement"
+              % (n_dev, args.gpus), file=sys.stderr)
+        env["VK_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)  # stdout / stderr inherited: the JSON line stays the last line
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,28 +269,25 @@ def main():
     if rehearsal:
         local_rank = 0
         os.environ["VK_BENCH_TRANSPORT"] = "torch"
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world  # (under a launcher the world it made is what runs)
     cfg = CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
     batch = args.batch or {"c2": 64, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 frames per launch: 0.0677 / 0.0659 / 0.0644 ms)
     if not args.batch and args.config == "c2" and world > 1:
-        # a rank's launch covers 1 / N of every frame: as many more frames keep it as long as the one-GPU launch, whose tail it
-        # would otherwise pay N times as often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at
-        # 16 / 32 / 64 / 128 frames per launch)
-        batch = min(256, 64 * world)  # (256: the most one vk_render_batch spans)
-    batch = max(1, min(batch, args.steps))
-    if not args.batch:
-        # K frames in ceil(K / batch) launches of (almost) equal size: a padded last launch would march frames nobody counts
-        n_launch = -(-args.steps // batch)
-        if world > 1 and args.steps >= 8:
-            # the gather of a launch hides behind the march of the next one: a timed region that is a single launch has
-            # nothing to hide behind (march, then wire, then un-tile, in series).  tools/small_k_emulation.py: at N = 8 two
-            # launches of 10 frames cost 2 x 0.21 ms of march against 0.31 ms for one of 20, and hide half of the wire time
-            n_launch = max(n_launch, 2)
-        batch = -(-args.steps // n_launch)
+        # a rank's launch covers 1 / N of every frame: more frames per launch keep it from paying the launch's tail N times as
+        # often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at 16 / 32 / 64 / 128 frames per launch)
+        batch = min(256, max(64, 32 * world))
+    batch = max(1, batch)
+    # ONE contiguous timed window (>= 100 timed frames): M = the multiple of K that covers max(100, four launches)
+    # -- march, wire and un-tile of different launches only overlap when a window holds several of them -- the same rule at
+    # every N and for the world-of-one driver line.  The window's M frames go out in launches of (almost) equal size: a padded
+    # last launch would march frames nobody counts.
+    K = max(1, args.steps)
+    timed_frames = K * -(-max(100, 4 * batch) // K)
+    n_launch = max(1, -(-timed_frames // batch))
+    batch = -(-timed_frames // n_launch)
+    if batch > 1024:
+        sys.exit("bench.py: --batch is at most 1024 frames per launch (VK_MAX_BATCH_FRAMES)")
 
     import torch
 
@@ -291,26 +328,27 @@ def main():
         ctx.update()
         pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
 
-        # untimed counting launch: the units one frame processes
-        s_ref, s_sampled = count_steps(ctx, V, flags)
-        # C2 is quoted on one camera.  The beyond-cache configurations march consecutive frames of an orbit instead (yaw step
-        # 2 pi / 1024): identical frames in one launch share their brick fetches in L2 / Infinity Cache and read up to 20 %
-        # faster than any real frame stream (tools/big_batch_orbit.py).  The step counts are then the mean over those frames.
-        cam_list = [blob] * batch
-        if args.config != "c2":
-            cam_list = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
-            tot_ref = tot_samp = 0
-            for cb in cam_list:
-                ctx.set_camera_blob(cb)
-                a, b = count_steps(ctx, V, flags)
-                tot_ref += a; tot_samp += b
-            ctx.set_camera_blob(blob)
-            s_ref, s_sampled = tot_ref // batch, tot_samp // batch
+        # untimed counting launches: the units one frame processes.  The config's own camera first (S_ref of THE frame BASELINE
+        # names, equal to the oracle's count) ...
+        s_ref_still, s_sampled_still = count_steps(ctx, V, flags)
+        # ... then the frames the timed launches march: consecutive frames of an orbit around that camera (yaw step 2 pi /
+        # 1024: src/camera.rs turns the camera on input), every frame its own camera.  A launch that repeats ONE camera skips
+        # the per-camera host work (tile order, cull rectangle, descriptors) and shares every fetch between its frames in
+        # L2 / Infinity Cache -- up to 20 % faster than any real frame stream on the beyond-cache configs
+        # (tools/big_batch_orbit.py), 3 % on C2; it is reported beside the headline as `still_camera`.
+        cam_list = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
+        tot_ref = tot_samp = 0
+        for cb in cam_list:
+            ctx.set_camera_blob(cb)
+            a, b = count_steps(ctx, V, flags)
+            tot_ref += a; tot_samp += b
+        ctx.set_camera_blob(blob)
+        s_ref, s_sampled = tot_ref / batch, tot_samp / batch  # means over the launch's frames
 
         launch_ev = []  # (start, end) HIP events around every batch launch of the timed region
         if not use_dist:
             frames = torch.empty((batch, H, W, 4), dtype=torch.float16, device="cuda")
-            cams = cam_list
+            cams_now = [cam_list]  # (swapped for the still-camera run)
             pending = [0]
 
             def submit(timed):
@@ -324,7 +362,7 @@ def main():
                 if timed:
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
-                V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=TILE)  # a partial batch is padded to a whole one
+                V.render_batch(ctx, pipe, cams_now[0], frames.data_ptr(), tile_size=TILE)  # a partial batch is padded to a whole one
                 if timed:
                     b.record(stream)
                     launch_ev.append((a, b))
@@ -352,12 +390,14 @@ def main():
                 btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport=transport, via_host=rehearsal)
 
             btr_i = [0]
+            cams_now = [cam_list]
 
             def submit(timed):
-                btr.submit(cam_list[btr_i[0] % batch]); btr_i[0] += 1
+                btr.submit(cams_now[0][btr_i[0] % batch]); btr_i[0] += 1
 
             def flush(timed=False):
                 btr.flush()
+                btr_i[0] = 0
 
         def timed_region(k, timed):
             torch.cuda.synchronize()
@@ -392,17 +432,25 @@ def main():
                 timed_region(batch, False)
             preroll_frames = (2 + n_pre) * batch
         timed_region(args.warmup, False) if args.warmup else None
-        # SURVEY 8(d) asks for >= 100 timed frames: with a smaller K the region of exactly K frames is repeated
-        # (and at least three times whatever K: a single region is at the mercy of one host hiccup -- a default run on a
-        # busy box once reported 27.5 ms of wall time around 20.3 ms of launches)
-        repeats = max(3, min(10, math.ceil(100 / max(args.steps, 1))))
-        runs = []
-        for _ in range(repeats):
-            del launch_ev[:]
-            runs.append((timed_region(args.steps, True), [(a, b) for a, b in launch_ev]))
-        run_order_ms = [r[0] / args.steps * 1e3 for r in runs]  # in the order they ran
-        runs.sort(key=lambda r: r[0])
-        elapsed, evs = runs[len(runs) // 2]
+        # The window of `timed_frames` frames, three times (a single window is at the mercy of one host hiccup -- a default
+        # run on a busy box once reported 27.5 ms of wall time around 20.3 ms of launches); the median is reported.
+        repeats = 3
+
+        def measure():
+            runs = []
+            for _ in range(repeats):
+                del launch_ev[:]
+                runs.append((timed_region(timed_frames, True), [(a, b) for a, b in launch_ev]))
+            order_ms = [r[0] / timed_frames * 1e3 for r in runs]  # in the order they ran
+            runs.sort(key=lambda r: r[0])
+            return runs[len(runs) // 2] + (order_ms,)
+
+        elapsed, evs, run_order_ms = measure()
+        # the same window with the config's ONE camera in every frame (what round 2 reported as the headline)
+        cams_now[0] = [blob] * batch
+        timed_region(batch, False)
+        still_elapsed, still_evs, _ = measure()
+        cams_now[0] = cam_list
         n_launch_frames = batch  # frames one launch spans
         launch_ms = None
         if evs:
@@ -410,15 +458,22 @@ def main():
             d = sorted(a.elapsed_time(b) for a, b in evs)
             launch_ms = sum(d) / len(d)
 
+        still_launch_ms = None
+        if still_evs:
+            torch.cuda.synchronize()
+            sd = sorted(a.elapsed_time(b) for a, b in still_evs)
+            still_launch_ms = sum(sd) / len(sd)
+
         if rank == 0:
             n_px = W * H
-            ms_per_step = elapsed / args.steps * 1e3
+            ms_per_step = elapsed / timed_frames * 1e3
             alg_frame = s_sampled * cfg["b_step"] + n_px * B_RAY
             out = {
                 "metric": cfg["metric"],
-                "value": s_ref * args.steps / elapsed / 1e6,
+                "value": s_ref * timed_frames / elapsed / 1e6,
                 "unit": "Mray-steps/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "timed_frames": timed_frames, "launches_per_region": n_launch, "frames_per_launch": batch,
                 "ms_per_step": ms_per_step,
                 "higher_is_better": True,
                 "scaling": "strong",
@@ -433,12 +488,19 @@ def main():
                     "partition": "one launch per batch of whole frames" if not use_dist else
                                  f"{TILE}x{TILE} tiles dealt heaviest-first over {world} ranks, one launch + one RCCL gather (second stream) + one un-tile per batch of {batch} frames",
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
-                    **({"cameras": "consecutive frames of an orbit, yaw step 2pi/1024 (step counts: mean over the launch's frames)"} if args.config != "c2" else {}),
+                    "s_ref_config_camera": s_ref_still, "s_sampled_config_camera": s_sampled_still,
+                    "cameras": "every frame its own camera: consecutive frames of an orbit around the config's camera, yaw step 2pi/1024 (step counts: mean over the launch's frames)",
+                    "window": "one contiguous window of %d frames = %d launches of %d (a multiple of --steps covering max(100, 4 launches))" % (timed_frames, n_launch, batch),
                     **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
                 **({"rehearsal": "all ranks on ONE GPU over gloo: a test of the N > 1 flow, not a measurement"} if rehearsal else {}),
                 "repeats": repeats, "repeat_ms_per_step": run_order_ms, "preroll_frames": preroll_frames,
                 "device": info["device_name"], "volume_setup_s": t_volume,
+                # the same window with the config's one camera repeated in every frame of every launch
+                "still_camera": {"ms_per_step": still_elapsed / timed_frames * 1e3, "value": s_ref_still * timed_frames / still_elapsed / 1e6,
+                                 "s_ref_per_frame": s_ref_still, "s_sampled_per_frame": s_sampled_still,
+                                 **({"launch_ms": still_launch_ms,
+                                     "frac": (s_sampled_still * cfg["b_step"] + n_px * B_RAY) * batch / (still_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if still_launch_ms else {})},
             }
             if launch_ms is not None:
                 alg = alg_frame * n_launch_frames
@@ -456,33 +518,40 @@ def main():
                     "achieved_at_reference_steps": (s_ref * cfg["b_step"] + n_px * B_RAY) * n_launch_frames / (launch_ms * 1e-3) / 1e9,
                 }
                 out["roofline"]["frac_at_reference_steps"] = out["roofline"]["achieved_at_reference_steps"] / HBM_PEAK_GBS
-                prof = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-                if os.path.exists(prof) and args.config == "c2" and not args.no_skip and args.layout == "auto":
+                # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/prof_traffic.sh)
+                # of THIS launch shape: the same orbit, the same number of frames per launch.  No figure for another shape is
+                # scaled to this one (round 2 did that); a shape that was not profiled reports null.
+                prof = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+                if os.path.exists(prof) and not args.no_skip and args.layout == "auto":
                     try:
-                        pj = json.load(open(prof))
-                        out["roofline"]["traffic"] = pj["hbm_bytes_per_frame"] * n_launch_frames
-                        out["roofline"]["traffic_source"] = pj.get("source", "profiles/r02_pmc_traffic.json")
-                        out["roofline"]["compulsory_GBps"] = (cfg["n"] ** 3 + n_px * B_RAY) * n_launch_frames / (launch_ms * 1e-3) / 1e9
+                        pj = json.load(open(prof)).get(args.config, {})
+                        ent = pj.get("per_frames_per_launch", {}).get(str(n_launch_frames))
+                        if ent is not None:
+                            out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                            out["roofline"]["traffic_source"] = ent.get("source", "profiles/r03_pmc_traffic.json")
+                        else:
+                            out["roofline"]["traffic_note"] = "no PMC pass at %d frames per launch (profiled: %s)" % (n_launch_frames, sorted(pj.get("per_frames_per_launch", {})))
+                        out["roofline"]["compulsory_GBps"] = (cfg["n"] ** 3 * (1 if cfg["fmt"] == "u8" else 2) + n_px * B_RAY * n_launch_frames) / (launch_ms * 1e-3) / 1e9
                     except Exception:
                         pass
             else:
                 # N > 1 (and --force-dist): march, gather and un-tile of different batches overlap on every rank, so no single
                 # kernel duration describes a step; the figure here is the whole job's algorithmic bytes over the wall time
                 # against N GPUs' HBM.  The per-kernel roofline is the N = 1 line's.
-                agg = alg_frame * args.steps / elapsed / 1e9
+                agg = alg_frame * timed_frames / elapsed / 1e9
                 out["roofline"] = {"bound": "hbm", "achieved": agg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": agg / (HBM_PEAK_GBS * world), "traffic": None,
                                    "kernel": "whole job (vk::raymarch_naive_kernel per rank + RCCL gather + un-tile, overlapped)",
-                                   "note": "aggregate over %d GPU(s): algorithmic bytes of K frames / wall time; per-kernel figure: see the N = 1 line" % world}
+                                   "note": "aggregate over %d GPU(s): algorithmic bytes of the window's frames / wall time; per-kernel figure: see the N = 1 line" % world}
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
                 out["config"]["root_skip"] = btr.root_skip
 
-        # untimed side measurements (rank 0, N = 1)
-        if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
-            extras = {}
-            # one frame per launch: the duration of a single-frame launch, its spread, and the no-skip / forced-skip kernels
+        # One frame per launch -- the reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) -- on the
+        # config's camera: duration of a single-frame launch and its spread, back to back on a busy GPU.
+        if rank == 0 and world == 1:
             try:
+                n1 = 100 if args.config == "c2" else 24
                 p1 = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
-                evs1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+                evs1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
                 for _ in range(5):
                     p1.record(ctx)
                 for a, b in evs1:
@@ -492,11 +561,16 @@ def main():
                 torch.cuda.synchronize()
                 d = sorted(a.elapsed_time(b) for a, b in evs1)
                 ms1 = sum(d) / len(d)
-                gb = (s_sampled * cfg["b_step"] + W * H * B_RAY) / (ms1 * 1e-3) / 1e9
-                extras["single_frame_launch"] = {"launch_ms": ms1, "launch_ms_p10": d[10], "launch_ms_p50": d[50], "launch_ms_p90": d[90],
-                                                 "Mray_steps_per_s": s_ref / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+                gb = (s_sampled_still * cfg["b_step"] + W * H * B_RAY) / (ms1 * 1e-3) / 1e9
+                out["single_frame"] = {"launch_ms": ms1, "launch_ms_p10": d[n1 // 10], "launch_ms_p50": d[n1 // 2], "launch_ms_p90": d[(9 * n1) // 10],
+                                       "value": s_ref_still / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
+                                       "note": "one vk_render per frame, the config's camera, %d launches back to back" % n1}
             except Exception as e:
-                extras["single_frame_launch"] = {"error": str(e)}
+                out["single_frame"] = {"error": str(e)}
+
+        # untimed side measurements (rank 0, N = 1)
+        if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
+            extras = {}
             try:
                 # the frame stream of an orbiting camera (src/camera.rs rotates on input): every frame of every batch its own
                 # camera, so the per-camera host work (tile order, cull rectangle, descriptors) is inside the wall time
@@ -561,20 +635,22 @@ def main():
                     dist.init_process_group("gloo", rank=0, world_size=1)
                     created = True
                 b1 = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root=0, transport="rccl")
-                for _ in range(2 * batch):
-                    b1.submit(blob)
+                for j in range(2 * batch):
+                    b1.submit(cam_list[j % batch])
                 b1.flush()
                 torch.cuda.synchronize()
-                kf = 8 * batch
-                t0 = time.perf_counter()
-                for _ in range(kf):
-                    b1.submit(blob)
-                b1.flush()
-                torch.cuda.synchronize()
-                msf = (time.perf_counter() - t0) / kf * 1e3
+                msfs = []
+                for _ in range(3):  # the headline's rule: the same orbit, one contiguous window of `timed_frames`, median of three
+                    t0 = time.perf_counter()
+                    for j in range(timed_frames):
+                        b1.submit(cam_list[j % batch])
+                    b1.flush()
+                    torch.cuda.synchronize()
+                    msfs.append((time.perf_counter() - t0) / timed_frames * 1e3)
+                msf = sorted(msfs)[1]
                 b1.close()
-                extras["dist_driver_world1"] = {"ms_per_frame": msf, "Mray_steps_per_s": s_ref / msf / 1e3, "frames_per_launch": batch,
-                                                "note": "BatchTileRenderer at world 1: compact tiles, gather to self, un-tile"}
+                extras["dist_driver_world1"] = {"ms_per_frame": msf, "Mray_steps_per_s": s_ref / msf / 1e3, "frames_per_launch": batch, "timed_frames": timed_frames,
+                                                "note": "BatchTileRenderer at world 1 on the headline's orbit and window: compact tiles, gather to self, un-tile"}
                 if created:
                     dist.destroy_process_group()
             except Exception as e:
@@ -632,7 +708,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c2":
             cb, s_cpu = cpu_baseline(blob)
             out["cpu_baseline"] = cb
-            out["cpu_baseline"]["s_ref_matches_gpu"] = (s_cpu == s_ref)
+            out["cpu_baseline"]["s_ref_matches_gpu"] = (s_cpu == s_ref_still)
         if use_dist:
             btr.close()
         ctx.close()

@@ -73,7 +73,8 @@ enum vk_render_flags {
     VK_RENDER_NO_SKIP = 1,  /* disable exact empty-space skipping (every step fetches taps) */
     VK_RENDER_COUNT = 2,    /* also accumulate step counters / per-pixel step counts */
     VK_RENDER_SAFE = 4,     /* force the clamped / 64-bit-offset kernel variant */
-    VK_RENDER_FORCE_SKIP = 8, /* use the skip kernel (with adaptive probing) whatever the census of transparent cells (default: from 30 %) */
+    VK_RENDER_FORCE_SKIP = 8, /* use the skip kernel (with adaptive probing) whatever the census of transparent cells (default policy:
+                                 dense kernel below 45 % of exactly transparent cells, adaptive probing from 45 %, probing on every trip from 55 %) */
     VK_RENDER_DEBUG_TRIPS = 16, /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
     VK_RENDER_DEBUG_FALLBACK = 32, /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
     VK_RENDER_PROBE_ALWAYS = 64 /* skip kernels: look the distance map up on every trip (no adaptive dense stretches): S_sampled is then
@@ -194,8 +195,10 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
  *     backbuffer's format.
  *   compact != 0: `out` receives this rank's tiles, [slot][frame][ts][ts] (slot j <-> position rank + j*nranks of
  *     that frame's order), slot < *n_active_slots <= slot_capacity: a contiguous prefix, ready for one gather.
- * *batch_id names the batch's tables for vk_untile_batch (the library holds the last 4).  VK_RENDER_COUNT is refused.
+ * n_frames <= VK_MAX_BATCH_FRAMES.  *batch_id names the batch's tables for vk_untile_batch (the library holds the last 4; a
+ * vk_backbuffer_resize or a new volume drops them all).  VK_RENDER_COUNT is refused.
  * Every frame is bitwise equal to the one vk_render produces for the same camera. */
+#define VK_MAX_BATCH_FRAMES 1024
 int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, uint32_t rank,
                     uint32_t nranks, float dt_scale, uint32_t flags, void *out, int compact, uint32_t slot_capacity,
                     uint32_t *batch_id, uint32_t *n_active_slots);

@@ -1324,11 +1324,16 @@ def test_procedural_partition(V, O):
         ctx.close()
 
 
-def test_bench_multi_rank_flow_rehearsal(V, O):
-    """bench.py's N > 1 flow end to end under torch.distributed.run with two ranks -- both on this one GPU, rendezvous over
-    gloo, tiles through torch.distributed (VK_BENCH_REHEARSAL): the launch line the driver uses, the weighted deal, the
-    pipelined gather + un-tile, max-over-ranks timing and the JSON contract.  (The library's RCCL communicator needs one GPU
-    per rank: world 1 in test_batch_tile_renderer_world1_rccl, more on the driver's 8-GPU node.)"""
+@pytest.mark.parametrize("how", ["plain", "torchrun"])
+def test_bench_multi_rank_flow_rehearsal(V, O, how):
+    """bench.py's N > 1 flow end to end with two ranks -- both on this one GPU, rendezvous over gloo, tiles through
+    torch.distributed (rehearsal): the weighted deal, the pipelined gather + un-tile, max-over-ranks timing, the contiguous
+    >= 100-frame window and the JSON contract.
+      plain:    `python bench.py --gpus 2 ...` typed exactly like the N = 1 line -- bench.py starts its own ranks as a child
+                torch.distributed.run (and, seeing one GPU for two ranks, rehearses);
+      torchrun: the launch line the driver uses for N > 1.
+    (The library's RCCL communicator needs one GPU per rank: world 1 in test_batch_tile_renderer_over_rccl_world1, its
+    multi-peer branches under the stand-in of test_multi_peer_branches_under_fake_rccl, real peers on the driver's 8-GPU node.)"""
     import json
     import os
     import socket
@@ -1336,18 +1341,45 @@ def test_bench_multi_rank_flow_rehearsal(V, O):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, VK_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--no-extras", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--no-extras", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VK_BENCH_REHEARSAL")}
+    if how == "plain":
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env["VK_BENCH_REHEARSAL"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 24 and d["warmup"] == 8 and d["unit"] == "Mray-steps/s" and d["value"] > 0
-    assert d["config"]["s_ref_per_frame"] == 148393048  # the C2 frame, as at N = 1
+    assert d["config"]["s_ref_config_camera"] == 148393048  # the C2 frame, as at N = 1
     assert "rehearsal" in d and d["config"]["transport"].startswith("torch.distributed")
-    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+    # one contiguous window of >= 100 frames and >= 4 launches, a multiple of --steps
+    assert d["timed_frames"] >= 100 and d["timed_frames"] % 24 == 0 and d["launches_per_region"] >= 4
+    assert d["frames_per_launch"] * d["launches_per_region"] >= d["timed_frames"]
+    assert abs(d["ms_per_step"] * d["timed_frames"] * 1e-3 * d["value"] * 1e6 / (d["config"]["s_ref_per_frame"] * d["timed_frames"]) - 1.0) < 1e-6
+    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "still_camera"):
         assert key in d, key
+
+
+def test_multi_peer_branches_under_fake_rccl(V, O):
+    """The branches that only run with more than one peer -- vk_group_render's n > 1 path and vk_gather_tiles' root branch --
+    executed on this one GPU through a single-process stand-in for RCCL (tests/fake_rccl.cpp, bound via VK_RCCL_LIB): n = 2, 3, 8
+    contexts, root_skip 0 / 2 / 3, every frame bitwise equal to vk_render's.  In a child process, so that this process keeps
+    the real RCCL for the other tests.  Generalises the reference's tile loop, examples/xor/main.rs:235-254."""
+    import os
+    import subprocess
+    import sys
+
+    import __graft_entry__ as g
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VK_RCCL_LIB=g.build_fake_rccl())
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "shim_multi_rank_check.py")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "shim_multi_rank_check: OK" in r.stdout, r.stdout
+    assert r.stdout.count("vk_group_render n=") == 9 and r.stdout.count("vk_gather_tiles n=") == 3, r.stdout

@@ -72,8 +72,7 @@ struct vk_ctx {
     hipStream_t ring_stream[16] = {};
     bool ring_done[16] = {};
     uint32_t ring_active[16] = {};   // order_active of the slot
-    uint32_t ring_epoch[16] = {};    // the epoch (count of order changes) that filled the slot
-    uint32_t order_epoch = 0;        // epoch of the current slot; epoch e lives in slot e % 16 while order_epoch - e < 16
+    uint32_t order_seq = 0;          // order changes so far; change e lives in slot e % 16
 
     // batched launches (vk_render_batch): per-batch tables {FrameDesc[B], order[B][n_tiles], pos[B][n_tiles]} in a small
     // ring of device slots fed from pinned staging; a slot is rewritten only after the last kernel that read it
@@ -82,8 +81,13 @@ struct vk_ctx {
         size_t cap = 0;
         hipEvent_t ev = nullptr;
         uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0, root_skip = 0;
+        uint32_t width = 0, height = 0;  // the frame shape and pixel format the batch was dealt for: an un-tile under another
+        int out_format = -1;             // shape (vk_backbuffer_resize in between) would scatter tiles out of bounds
     } batch[4];
     uint32_t batch_seq = 0;
+    // table blocks a growing batch has outgrown: hipFree / hipHostFree synchronise the device, so they wait here for a
+    // call that synchronises anyway (vk_backbuffer_resize, vk_ctx_destroy) instead of stalling four launches in flight
+    std::vector<std::pair<void *, void *>> batch_retired;
     // the order of the last camera a batch computed one for (a still camera costs no host work from batch to batch)
     std::vector<unsigned char> batch_key;
     std::vector<uint32_t> batch_order, batch_pos;
@@ -109,6 +113,7 @@ struct vk_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 0;
     bool comm_owned = false;
+    bool in_group = false;  // a member of a vk_group: its communicator belongs to the group's world
 };
 
 static thread_local std::string g_create_err;
@@ -149,9 +154,17 @@ static RcclApi g_rccl;
 
 static bool rccl_load() {
     if (g_rccl.lib) return true;
+    // VK_RCCL_LIB names the library to bind instead (a particular RCCL build; the test suite's single-process stand-in,
+    // tests/fake_rccl.cpp, through which the N > 1 branches below run on a one-GPU box).  It is taken or refused -- no
+    // silent return to the system's copy.
     const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void *h = nullptr;
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    const char *forced = std::getenv("VK_RCCL_LIB");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { g_rccl.err = std::string("VK_RCCL_LIB=") + forced + ": " + dlerror(); return false; }
+    }
+    for (const char *n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
     if (!h) { g_rccl.err = std::string("RCCL not found: ") + dlerror(); return false; }
     auto sym = [&](const char *n) -> void * { void *p = dlsym(h, n); if (!p) g_rccl.err = std::string("RCCL symbol missing: ") + n; return p; };
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -258,6 +271,7 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (ctx->d_ring) (void)hipFree(ctx->d_ring);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     for (auto &b : ctx->batch) { if (b.d) (void)hipFree(b.d); if (b.h) (void)hipHostFree(b.h); if (b.ev) (void)hipEventDestroy(b.ev); }
+    for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
     for (hipEvent_t e : ctx->ring_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -326,6 +340,8 @@ static void free_volume(vk_ctx *ctx);
 
 static int commit_volume(vk_ctx *ctx, VolBuild &nb) {
     free_volume(ctx);
+    for (auto &b : ctx->batch) b.id = 0;  // batches dealt for the previous volume are no longer un-tiled
+    ctx->batch_key.clear();
     ctx->vol = nb.vol; ctx->vol2 = nb.vol2; ctx->dist = nb.dist; ctx->lut = nb.lut;
     for (int k = 0; k < 3; k++) ctx->scopy[k] = nb.scopy[k];
     ctx->vol_bytes = nb.vol_bytes;
@@ -704,6 +720,10 @@ int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_f
     if (out_format != VK_OUT_RGBA32F && out_format != VK_OUT_RGBA16F) return fail(ctx, VK_ERR_INVALID, "unknown output format");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &b : ctx->batch) b.id = 0;  // batch ids held by the caller named tiles of the old shape
+    ctx->batch_key.clear();
+    for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
+    ctx->batch_retired.clear();
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
     if (ctx->steps) (void)hipFree(ctx->steps);
     ctx->backbuffer = nullptr;
@@ -1012,13 +1032,12 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
         if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
         ctx->d_ring = ctx->h_ring = nullptr; ctx->d_order = ctx->d_order_pos = nullptr;
         ctx->d_order_cap = 0; ctx->ring_slot = -1;
-        for (uint32_t &e : ctx->ring_epoch) e = 0;  // older epochs are gone with the old ring
         HIP_TRY(ctx, hipMalloc(&ctx->d_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
         HIP_TRY(ctx, hipHostMalloc(&ctx->h_ring, (size_t)kOrderRing * 2 * n * sizeof(uint32_t)));
         ctx->d_order_cap = n;
     }
     const size_t cap = ctx->d_order_cap;
-    const int slot = (int)((ctx->order_epoch + 1u) % (uint32_t)kOrderRing);  // epoch e lives in slot e % kOrderRing
+    const int slot = (int)(++ctx->order_seq % (uint32_t)kOrderRing);
     // Waiting on the slot's previous upload (kOrderRing cameras ago) makes the pinned staging safe to rewrite.  The
     // device slot itself is safe to overwrite because a context works on ONE stream: the kernels that read the slot
     // kOrderRing cameras ago were enqueued on ctx->stream before this copy (vk_ctx_set_stream drains the old stream
@@ -1034,7 +1053,6 @@ static int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint
     ctx->ring_stream[slot] = ctx->stream;
     ctx->ring_done[slot] = false;
     ctx->ring_active[slot] = n_active;
-    ctx->ring_epoch[slot] = ++ctx->order_epoch;
     ctx->ring_slot = slot;
     ctx->d_order = ds;
     ctx->d_order_pos = ds + cap;
@@ -1389,7 +1407,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
                     float dt_scale, uint32_t flags, void *out, int compact, uint32_t slot_capacity, uint32_t *batch_id, uint32_t *n_active_slots) {
     if (!ctx) return VK_ERR_INVALID;
     if (!cameras || !out) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: NULL argument");
-    if (n_frames == 0 || n_frames > 256) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: 1..256 frames per batch");
+    if (n_frames == 0 || n_frames > VK_MAX_BATCH_FRAMES) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: 1..1024 frames per batch");
     if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: the step counters describe one frame; count with vk_render");
     if (!compact && nranks != 1) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: whole frames need nranks == 1; a rank's share is compact");
     const float *cams = reinterpret_cast<const float *>(cameras);
@@ -1410,13 +1428,17 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     vk_ctx::BatchSlot &B = ctx->batch[ctx->batch_seq % 4u];
     if (B.ev) HIP_TRY(ctx, hipEventSynchronize(B.ev));  // the launches of four batches ago have long finished
     else HIP_TRY(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+    B.id = 0;  // claimed: whatever fails below, the slot no longer answers to its old id
     if (B.cap < bytes) {
-        if (B.d) (void)hipFree(B.d);
-        if (B.h) (void)hipHostFree(B.h);
-        B.d = B.h = nullptr; B.cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&B.d, bytes));
-        HIP_TRY(ctx, hipHostMalloc((void **)&B.h, bytes));
-        B.cap = bytes;
+        // sized for 256 frames from the start and doubled from there; the outgrown blocks are retired, not freed (hipFree and
+        // hipHostFree synchronise the device: a driver whose batches grow -- 20, then 32 frames -- stalled four launches each time)
+        if (B.d || B.h) ctx->batch_retired.emplace_back(B.d, B.h);
+        B.d = B.h = nullptr;
+        const size_t want = std::max({bytes, 2 * B.cap, (size_t)256 * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t))});
+        B.cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&B.d, want));
+        HIP_TRY(ctx, hipHostMalloc((void **)&B.h, want));
+        B.cap = want;
     }
     FrameDesc *fd = reinterpret_cast<FrameDesc *>(B.h);
     uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
@@ -1481,6 +1503,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     HIP_TRY(ctx, hipMemcpyAsync(B.d, B.h, bytes, hipMemcpyHostToDevice, ctx->stream));
     B.id = ++ctx->batch_seq;
     B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active; B.root_skip = root_skip;
+    B.width = ctx->width; B.height = ctx->height; B.out_format = ctx->out_format;
     if (batch_id) *batch_id = B.id;
     // whole frames: the tiles behind a frame's active positions get their clear colour from strips at the end of the grid
     const uint32_t clear_max_inactive = (!compact && geo_mode == VK_MODE_NAIVE_TRILINEAR && min_active < n_tiles) ? (uint32_t)n_tiles - min_active : 0u;
@@ -1523,7 +1546,10 @@ int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, u
     // written again.  A batch of another shape, or one no longer held, is simply not used.
     if (prev_batch_id != 0)
         for (auto &b : ctx->batch) if (b.id == prev_batch_id) P = &b;
-    if (P && (P->n_frames != B->n_frames || P->n_tiles != B->n_tiles || P->ts != B->ts || !P->d)) P = nullptr;
+    if (B->width != ctx->width || B->height != ctx->height || B->out_format != ctx->out_format)
+        return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: the backbuffer changed shape or format since that batch was dealt");
+    if (P && (P->n_frames != B->n_frames || P->n_tiles != B->n_tiles || P->ts != B->ts || P->width != B->width || P->height != B->height ||
+              P->out_format != B->out_format || !P->d)) P = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t tx = (ctx->width + B->ts - 1) / B->ts;
     const uint32_t chunks = (B->ts * B->ts + 511u) / 512u;
@@ -1586,6 +1612,7 @@ int vk_comm_unique_id(void *id128) {
 int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks) {
     if (!ctx || !id128) return fail(ctx, VK_ERR_INVALID, "vk_comm_init_rank: NULL argument");
     if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, VK_ERR_INVALID, "vk_comm_init_rank: rank/nranks");
+    if (ctx->in_group) return fail(ctx, VK_ERR_INVALID, "vk_comm_init_rank: this context belongs to a vk_group (its communicator is the group's)");
     if (!rccl_load()) return fail(ctx, VK_ERR_UNSUPPORTED, g_rccl.err);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     comm_release(ctx);
@@ -1598,6 +1625,7 @@ int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks) {
 
 int vk_comm_destroy(vk_ctx *ctx) {
     if (!ctx) return VK_ERR_INVALID;
+    if (ctx->in_group) return fail(ctx, VK_ERR_INVALID, "vk_comm_destroy: this context belongs to a vk_group (vk_group_destroy releases it)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     comm_release(ctx);
@@ -1667,6 +1695,7 @@ int vk_group_create(int n, const int *ordinals, vk_group **out) {
         vk_ctx *c = nullptr;
         int rc = vk_ctx_create(ordinals[i], &c);
         if (rc) return bail(rc, std::string("vk_group_create: ") + vk_last_error(nullptr));
+        c->in_group = true;
         g->ctx.push_back(c);
     }
     if (n > 1) {

@@ -146,20 +146,27 @@ class BatchTileRenderer:
         self.comm_stream = torch.cuda.Stream()
         self.transport = transport
         if transport == "rccl":
-            # the library's own communicator: rank 0 makes the id, torch.distributed (already up) ships its 128 bytes
+            # The library's own communicator: rank 0 makes the id, torch.distributed (already up) ships its 128 bytes.
+            # ncclCommInitRank blocks until every rank has joined, so no rank may enter it unless all of them can: every
+            # rank first proves that it can load and call RCCL (its own throw-away id) and the ranks agree on that; they
+            # agree again on the outcome of the join itself.  A rank that fails raises on EVERY rank instead of leaving its
+            # peers parked inside a collective.
             idbuf = (C.c_ubyte * 128)()
-            obj = [None]
-            if self.rank == 0:
-                try:  # a failure here must still reach the broadcast: the other ranks are waiting in it
-                    N.check(None, N.lib().vk_comm_unique_id(idbuf))
-                    obj = [bytes(idbuf)]
-                except Exception as e:  # noqa: BLE001
-                    obj = ["rank 0 could not make a communicator id: %r" % (e,)]
+            why = None
+            try:
+                N.check(None, N.lib().vk_comm_unique_id(idbuf))
+            except Exception as e:  # noqa: BLE001
+                why = "rank %d cannot use RCCL: %r" % (self.rank, e)
+            self._agree(why, "loading RCCL")
+            obj = [bytes(idbuf) if self.rank == 0 else None]
             if self.world > 1:
                 dist.broadcast_object_list(obj, src=0, group=group)
-            if not isinstance(obj[0], bytes):
-                raise RuntimeError(obj[0])
-            N.check(ctx.handle, N.lib().vk_comm_init_rank(ctx.handle, obj[0], self.rank, self.world))
+            why = None
+            try:
+                N.check(ctx.handle, N.lib().vk_comm_init_rank(ctx.handle, obj[0], self.rank, self.world))
+            except Exception as e:  # noqa: BLE001
+                why = "rank %d could not join the communicator: %r" % (self.rank, e)
+            self._agree(why, "joining the communicator")
             self.tg = None
         elif transport == "torch":
             self.tg = TorchTileGather(group, root, via_host)
@@ -193,37 +200,60 @@ class BatchTileRenderer:
     def is_root(self) -> bool:
         return self.rank == self.root
 
+    def _agree(self, why, what: str):
+        """Every rank reaches this point with its own outcome (`why`: None = fine); all of them leave it with the same
+        verdict: either nobody failed, or everybody raises with the failing ranks' messages."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            if why is not None:
+                raise RuntimeError(why)
+            return
+        all_why = [None] * self.world
+        dist.all_gather_object(all_why, why, group=self._group)
+        bad = [w for w in all_why if w is not None]
+        if bad:
+            raise RuntimeError("%s failed on %d of %d ranks: %s" % (what, len(bad), self.world, "; ".join(bad)))
+
     def _calibrate_root_skip(self) -> int:
         """k = (M + U) / (U * world) balances the root's march share + un-tile against a peer's share, with M the time
         to march one whole frame's tiles and U the time to un-tile one frame, both measured here on a 4-frame batch."""
         import torch.distributed as dist
 
-        torch = self.torch
         if self.world == 1 or self.root != 0:  # (uniform over the ranks: everybody joins the broadcast below)
             return 0
         k = [0]
         if self.is_root and self.ctx.camera_blob is not None:
-            B = min(4, self.batch)
-            cap1 = partition_slots(self.W, self.H, self.ts, 1)
-            tiles = torch.zeros((cap1, B, self.ts, self.ts, 4), dtype=self.dtype, device=self.dev)
-            frames = torch.zeros((B, self.H, self.W, 4), dtype=self.dtype, device=self.dev)
-            cams = [self.ctx.camera_blob] * B
-            self.ctx.set_root_skip(0)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            for it in range(2):  # the second pass is the measurement
-                ev[0].record()
-                bid, act = render_batch(self.ctx, self.pipe, cams, tiles.data_ptr(), tile_size=self.ts, rank=0, nranks=1, compact=True, slot_capacity=cap1)
-                ev[1].record()
-                untile_batch(self.ctx, bid, tiles.data_ptr(), act, frames.data_ptr())
-                ev[2].record()
-                torch.cuda.current_stream().synchronize()
-            m, u = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-            if u > 0 and m > 0:
-                kk = int(round((m + u) / (u * self.world)))
-                k[0] = 0 if kk > 64 else max(2, kk)
-            del tiles, frames
+            try:  # (a failure here must still reach the broadcast: the other ranks are waiting in it)
+                k[0] = self._measure_root_share()
+            except Exception as e:  # noqa: BLE001
+                k[0] = "calibration of the root's share failed on the root: %r" % (e,)
         dist.broadcast_object_list(k, src=self.root, group=self._group)
+        if isinstance(k[0], str):
+            raise RuntimeError(k[0])
         return int(k[0])
+
+    def _measure_root_share(self) -> int:
+        torch = self.torch
+        B = min(4, self.batch)
+        cap1 = partition_slots(self.W, self.H, self.ts, 1)
+        tiles = torch.zeros((cap1, B, self.ts, self.ts, 4), dtype=self.dtype, device=self.dev)
+        frames = torch.zeros((B, self.H, self.W, 4), dtype=self.dtype, device=self.dev)
+        cams = [self.ctx.camera_blob] * B
+        self.ctx.set_root_skip(0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for _ in range(2):  # the second pass is the measurement
+            ev[0].record()
+            bid, act = render_batch(self.ctx, self.pipe, cams, tiles.data_ptr(), tile_size=self.ts, rank=0, nranks=1, compact=True, slot_capacity=cap1)
+            ev[1].record()
+            untile_batch(self.ctx, bid, tiles.data_ptr(), act, frames.data_ptr())
+            ev[2].record()
+            torch.cuda.current_stream().synchronize()
+        m, u = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        if not (u > 0 and m > 0):
+            return 0
+        kk = int(round((m + u) / (u * self.world)))
+        return 0 if kk > 64 else max(2, kk)
 
     def submit(self, camera_blob: bytes | None = None):
         blob = camera_blob if camera_blob is not None else self.ctx.camera_blob
