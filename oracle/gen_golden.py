@@ -51,7 +51,12 @@ CAMERAS = {
 }
 
 
-def main():
+def main(out_dir: str | None = None):
+    """Writes the fixtures into `out_dir` (default: tests/golden).  tests/test_oracle_cpu.py::test_golden_volumes_rebuild runs
+    it into a scratch directory and holds the committed fixtures to what it produces today."""
+    global OUT
+    if out_dir is not None:
+        OUT = out_dir
     os.makedirs(OUT, exist_ok=True)
     cams = {k: O.camera_blob(*v) for k, v in CAMERAS.items()}
     np.savez_compressed(os.path.join(OUT, "cameras.npz"), **{k: np.frombuffer(v, np.uint8) for k, v in cams.items()})

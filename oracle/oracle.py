@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "_build", "libvokselis_oracle.so")
 FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR = 0, 1, 2
 MODE_NAIVE_TRILINEAR, MODE_COMPUTE_NEAREST, MODE_PROCEDURAL = 0, 1, 2
 FLAG_NO_EARLY_OUT, FLAG_TAPNORM_PER_TAP = 1, 2
+FLAG_LITERAL_WGSL, FLAG_TRANSFER_R1 = 8, 16  # yardsticks: the shader's text as written / the round-1 text of the transfer function
 
 
 class CameraUniform(C.Structure):
@@ -81,6 +82,10 @@ def lib() -> C.CDLL:
         L.vo_sample_trilinear.restype = C.c_float
         L.vo_transfer_alpha.argtypes = [C.c_float, C.c_int]
         L.vo_transfer_alpha.restype = C.c_float
+        L.vo_transfer_alpha_r1.argtypes = [C.c_float, C.c_int]
+        L.vo_transfer_alpha_r1.restype = C.c_float
+        L.vo_transfer_alpha_literal.argtypes = [C.c_float]
+        L.vo_transfer_alpha_literal.restype = C.c_float
         L.vo_vertigo.argtypes = [C.c_float, C.POINTER(C.c_float)]
         L.vo_linear_to_srgb.argtypes = [C.c_float]
         L.vo_linear_to_srgb.restype = C.c_float

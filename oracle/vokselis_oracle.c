@@ -222,10 +222,11 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 
 float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz, int format,
                           const float p[3], int flags, int *any_nonempty) {
-    /* u = p*n - 0.5 as ONE fused op (texel-space coordinate of the sample) */
-    float ux = fmaf(p[0], (float)nx, -0.5f);
-    float uy = fmaf(p[1], (float)ny, -0.5f);
-    float uz = fmaf(p[2], (float)nz, -0.5f);
+    /* u = p*n - 0.5 as ONE fused op (texel-space coordinate of the sample); the literal reading multiplies, then subtracts */
+    const int literal = (flags & VO_FLAG_LITERAL_WGSL) != 0;
+    float ux = literal ? p[0] * (float)nx - 0.5f : fmaf(p[0], (float)nx, -0.5f);
+    float uy = literal ? p[1] * (float)ny - 0.5f : fmaf(p[1], (float)ny, -0.5f);
+    float uz = literal ? p[2] * (float)nz - 0.5f : fmaf(p[2], (float)nz, -0.5f);
     float flx = floorf(ux), fly = floorf(uy), flz = floorf(uz);
     /* fractional weights: fract(u) = min(u - floor(u), 1 - 2^-24), the GPU fract semantic
      * (bit-identical to gfx950 v_fract_f32; checked exhaustively by tools/ubench/semantics.hip) */
@@ -252,7 +253,7 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
         for (int k = 0; k < 8; k++) {
             uint8_t c = v[idx[k]];
             nonempty |= (c > 25);
-            t[k] = (flags & VO_FLAG_TAPNORM_PER_TAP) ? (float)c / 255.0f : (float)c;
+            t[k] = (flags & (VO_FLAG_TAPNORM_PER_TAP | VO_FLAG_LITERAL_WGSL)) ? (float)c / 255.0f : (float)c;
         }
     } else {
         const uint16_t *v = (const uint16_t *)vol;
@@ -262,6 +263,14 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
         }
     }
     if (any_nonempty) *any_nonempty = nonempty;
+    if (literal) {
+        /* no fused operation anywhere: a + f * (b - a), product and sum rounded separately; R8Unorm taps were normalised
+         * one by one above (c / 255 as a true divide), so nothing is left to scale */
+        float c00 = t[0] + fx * (t[1] - t[0]), c10 = t[2] + fx * (t[3] - t[2]);
+        float c01 = t[4] + fx * (t[5] - t[4]), c11 = t[6] + fx * (t[7] - t[6]);
+        float c0 = c00 + fy * (c10 - c00), c1 = c01 + fy * (c11 - c01);
+        return c0 + fz * (c1 - c0);
+    }
     /* lerp x, then y, then z; lerp(a,b,f) = fma(f, b-a, a) */
     float c00 = lerp_fma(t[0], t[1], fx), c10 = lerp_fma(t[2], t[3], fx);
     float c01 = lerp_fma(t[4], t[5], fx), c11 = lerp_fma(t[6], t[7], fx);
@@ -293,6 +302,29 @@ float vo_transfer_alpha(float x, int raw_unorm8) {
     float s = fmaf(vmin(x, c), k1, k2);
     s = vmin(vmax(s, 0.0f), 1.0f);
     return (s * s) * fmaf(-2.0f, s, 3.0f);
+}
+
+/* The round-1 text of the same function (oracle history: replaced by the fused form above in round 2, goldens regenerated
+ * then): R8Unorm normalised by one multiply with f32(1/255) after the filter, v = min(0.9, r), s = (v - 0.1) * f32(1 / 1.1)
+ * -- three roundings where the current text has one -- then the same clamp and cubic.  Kept as the yardstick that bounds how
+ * far the re-specification moved alpha (tests/test_oracle_cpu.py::test_transfer_respecification_is_bounded). */
+float vo_transfer_alpha_r1(float x, int raw_unorm8) {
+    float r = raw_unorm8 ? x * (1.0f / 255.0f) : x;
+    float v = vmin(0.9f, r);
+    const float inv = 1.0f / (1.2f - 0.10f);
+    float s = (v - 0.10f) * inv;
+    s = vmin(vmax(s, 0.0f), 1.0f);
+    return (s * s) * fmaf(-2.0f, s, 3.0f);
+}
+
+/* raycast_naive.wgsl:106-107 AS WRITTEN, no licence taken: x is a normalised value; clamp(0.4, 0.9, val) read as
+ * min(0.9, val) (SURVEY F8 -- that one reading is not negotiable, bonsai.png rules the other out); smoothstep with its divide,
+ * t = clamp((v - 0.10) / (1.2 - 0.10), 0, 1), t * t * (3 - 2 t), every operation rounded separately. */
+float vo_transfer_alpha_literal(float x) {
+    float v = vmin(0.9f, x);
+    float s = (v - 0.10f) / (1.2f - 0.10f);
+    s = vmin(vmax(s, 0.0f), 1.0f);
+    return s * s * (3.0f - 2.0f * s);
 }
 
 void vo_vertigo(float a, float rgb[3]) {
@@ -385,18 +417,29 @@ static void pixel_naive(const vo_render_args *a, uint32_t x, uint32_t y, float o
     uint32_t n = 0, ns = 0;
     for (float t = th[0]; t < th[1]; t = t + dt) { /* :101 */
         int nonempty = 0;
-        const int raw8 = a->format == VO_FMT_R8_UNORM && !(a->flags & VO_FLAG_TAPNORM_PER_TAP);
+        const int literal = (a->flags & VO_FLAG_LITERAL_WGSL) != 0;
+        const int raw8 = a->format == VO_FMT_R8_UNORM && !(a->flags & (VO_FLAG_TAPNORM_PER_TAP | VO_FLAG_LITERAL_WGSL));
         float r = vo_sample_trilinear(a->volume, a->nx, a->ny, a->nz, a->format, p, a->flags | VO_FLAG_RAW_UNORM8, &nonempty);
-        float al = vo_transfer_alpha(r, raw8);
+        float al = literal ? vo_transfer_alpha_literal(r) : ((a->flags & VO_FLAG_TRANSFER_R1) ? vo_transfer_alpha_r1(r, raw8) : vo_transfer_alpha(r, raw8));
         float rgb[3];
         vo_vertigo(al, rgb);
         n++;
         ns += (uint32_t)nonempty;
         /* :112-114; background term is identically +0 (tex.a == 1 for a one-channel format) */
         float w = (1.0f - A) * al;
-        C[0] = C[0] + w * rgb[0];
-        C[1] = C[1] + w * rgb[1];
-        C[2] = C[2] + w * rgb[2];
+        if (literal) {
+            /* :104,112 word for word: val_alpha = pow(tex.a, 2) with tex.a = 1 for a one-channel format, and the background term
+             * background.rgb * background.a * (1 - val_alpha) added to every channel (it is +0: kept so that nothing is assumed) */
+            const float bg[4] = {0.1f, 0.2f, 0.3f, 0.01f};
+            const float val_alpha = powf(1.0f, 2.0f);
+            C[0] = C[0] + w * rgb[0] + bg[0] * bg[3] * (1.0f - val_alpha);
+            C[1] = C[1] + w * rgb[1] + bg[1] * bg[3] * (1.0f - val_alpha);
+            C[2] = C[2] + w * rgb[2] + bg[2] * bg[3] * (1.0f - val_alpha);
+        } else {
+            C[0] = C[0] + w * rgb[0];
+            C[1] = C[1] + w * rgb[1];
+            C[2] = C[2] + w * rgb[2];
+        }
         A = A + w;
         if (A >= 0.95f && !(a->flags & VO_FLAG_NO_EARLY_OUT)) break; /* :115-117 */
         p[0] = p[0] + step[0];

@@ -56,7 +56,13 @@ enum { VO_MODE_NAIVE_TRILINEAR = 0, VO_MODE_COMPUTE_NEAREST = 1, VO_MODE_PROCEDU
 enum {
     VO_FLAG_NO_EARLY_OUT = 1, /* count/march S_nominal: ignore the alpha>=0.95 break */
     VO_FLAG_TAPNORM_PER_TAP = 2, /* ablation: normalise u8 taps (c/255) before the lerps */
-    VO_FLAG_RAW_UNORM8 = 4 /* vo_sample_trilinear: leave filtered R8Unorm taps on their 0..255 scale (the march's own call) */
+    VO_FLAG_RAW_UNORM8 = 4, /* vo_sample_trilinear: leave filtered R8Unorm taps on their 0..255 scale (the march's own call) */
+    /* NAIVE mode: evaluate raycast_naive.wgsl:96-119 AS WRITTEN instead of as specified -- texel coordinate p*n - 0.5 with two
+     * roundings, every R8Unorm tap divided by 255, lerps a + f*(b - a) without fused operations, smoothstep's (v - 0.1) / (1.2 -
+     * 0.1) as a true divide, the background term kept, libm cosf / powf.  The yardstick for the distance between "what the
+     * shader says" and "what the three implementations agree on" (DESIGN.md 2.1); never the checker of the HIP path. */
+    VO_FLAG_LITERAL_WGSL = 8,
+    VO_FLAG_TRANSFER_R1 = 16 /* NAIVE mode: the round-1 text of the transfer function (vo_transfer_alpha_r1) in an otherwise specified march */
 };
 
 typedef struct vo_render_args {
@@ -94,6 +100,8 @@ float vo_sample_trilinear(const void *vol, uint32_t nx, uint32_t ny, uint32_t nz
 
 /* shaders/raycast_naive.wgsl:106-107 (clamp with low>high read as min(0.9,v)). */
 float vo_transfer_alpha(float x, int raw_unorm8);
+float vo_transfer_alpha_r1(float x, int raw_unorm8); /* the round-1 text (three roundings); yardstick only */
+float vo_transfer_alpha_literal(float x);            /* the shader's text with its divide; yardstick only */
 /* shaders/raycast_naive.wgsl:70-81. */
 void vo_vertigo(float a, float rgb[3]);
 /* shaders/raycast_naive.wgsl:63-68. */

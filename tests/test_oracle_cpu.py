@@ -214,3 +214,75 @@ def test_xor_generator_oracle(O):
     assert np.isnan(n3[r > 0.51]).all()                     # normalize(0): the reference stores NaN there too
     ok = ~np.isnan(n3).any(axis=-1)
     assert np.abs(np.linalg.norm(n3[ok], axis=-1) - 1).max() < 2e-3
+
+
+def test_golden_volumes_rebuild(tmp_path, golden_volumes):
+    """The committed fixtures are what oracle/gen_golden.py produces TODAY: regenerate into a scratch directory and compare
+    every array bit for bit (a fixture edited by hand, or a specification changed without regenerating, fails here); and the
+    closed-form volumes the tests rebuild (conftest.adversarial_volumes) are the generator's own."""
+    import os
+
+    from oracle import gen_golden as G
+
+    from conftest import GOLDEN, adversarial_volumes
+
+    G.main(str(tmp_path))
+    names = sorted(n for n in os.listdir(GOLDEN) if n.endswith(".npz"))
+    assert names == sorted(n for n in os.listdir(tmp_path) if n.endswith(".npz"))
+    for n in names:
+        a, b = np.load(os.path.join(GOLDEN, n)), np.load(os.path.join(tmp_path, n))
+        assert sorted(a.files) == sorted(b.files), n
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), (n, k)
+    mine, theirs = adversarial_volumes(32), G.adversarial_volumes(32)
+    assert sorted(mine) == sorted(theirs)
+    for k in mine:
+        assert (mine[k] == theirs[k]).all(), k
+
+
+def test_transfer_respecification_is_bounded(O, cameras, golden_volumes):
+    """Round 2 re-specified the transfer function (one fused op carrying the sample's scale; goldens regenerated).  The
+    round-1 text is kept as vo_transfer_alpha_r1: over EVERY u8-scale input on a fine grid and every finite non-negative
+    f16 the two differ by at most 2 ulp of alpha's range, and on the golden cameras the two formulations give identical
+    per-pixel trip counts and images within 2e-6 -- the re-specification moved no exit and no pixel beyond rounding."""
+    L = O.lib()
+    xs = np.concatenate([np.arange(0, 256, dtype=np.float32), np.linspace(0, 255, 100001, dtype=np.float32)])
+    assert max(abs(L.vo_transfer_alpha(float(x), 1) - L.vo_transfer_alpha_r1(float(x), 1)) for x in xs) <= 2.5e-7
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    assert max(abs(L.vo_transfer_alpha(float(x), 0) - L.vo_transfer_alpha_r1(float(x), 0)) for x in h) <= 2.5e-7
+    # exact zeros: what the skip maps call transparent (every tap <= 25) is exactly transparent under both texts; the one input
+    # on which they part is the threshold itself, x = 25.5 = 0.1 * 255, where f32(25.5 * f32(1/255)) lands one ulp above 0.1f:
+    # the round-1 text answers 1.4e-16 there, the fused one 0 -- fourteen orders of magnitude below anything a pixel shows
+    for x in (0.0, 25.0, 25.49):
+        assert L.vo_transfer_alpha(x, 1) == 0.0 and L.vo_transfer_alpha_r1(x, 1) == 0.0
+    assert L.vo_transfer_alpha(25.5, 1) == 0.0 and 0.0 <= L.vo_transfer_alpha_r1(25.5, 1) < 1e-15
+    assert L.vo_transfer_alpha(26.0, 1) > 0.0 and L.vo_transfer_alpha_r1(26.0, 1) > 0.0
+    for cam in ("bonsai_1x1", "inside", "axis"):
+        for name in ("standin", "ramp_x", "checker", "fog"):
+            for dt in (1.0, 0.5):
+                a, sa, _ = O.render(cameras[cam], golden_volumes[name], 64, 64, dt_scale=dt)
+                b, sb, _ = O.render(cameras[cam], golden_volumes[name], 64, 64, dt_scale=dt, flags=O.FLAG_TRANSFER_R1)
+                assert (sa == sb).all(), (cam, name, dt)
+                assert np.abs(a - b).max() <= 2e-6, (cam, name, dt)
+
+
+def test_literal_wgsl_yardstick(O):
+    """VO_FLAG_LITERAL_WGSL evaluates raycast_naive.wgsl:96-119 as written (unfused p*n - 0.5, every tap / 255, unfused lerps,
+    smoothstep with its divide, the background term, libm cos / pow); the specified reading (fused coordinate, one scale,
+    one-fma transfer) is what oracle, numpy restatement and HIP kernels share.  Distance between the two on C1 (512x512,
+    dt_scale 1) and on a 640x480 crop of C2 (1920x1080, dt_scale 0.5), bonsai stand-in 256^3: NO pixel changes its trip
+    count, max |dRGBA| 1.4e-6 (bar: 1e-4) -- the numbers DESIGN.md 2.1 quotes."""
+    vol = O.volume_standin_u8(256)
+    for W, H, dt, aspect, tile in ((512, 512, 1.0, 1.0, None), (1920, 1080, 0.5, 16 / 9, (640, 300, 640, 480))):
+        blob = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), aspect)
+        a, sa, _ = O.render(blob, vol, W, H, dt_scale=dt, tile=tile)
+        b, sb, _ = O.render(blob, vol, W, H, dt_scale=dt, tile=tile, flags=O.FLAG_LITERAL_WGSL)
+        differ = np.argwhere(sa != sb)
+        assert len(differ) <= 16, differ[:20]  # (measured: none)
+        same = sa == sb
+        assert np.abs(a - b)[same].max() <= 1e-5 and np.abs(a - b).max() <= 1e-4
+        assert (sa > 0).sum() > 100000
+    # the transfer function alone, every input: |alpha_specified - alpha_literal| stays at rounding level
+    L = O.lib()
+    xs = np.linspace(0, 255, 50001, dtype=np.float32)
+    assert max(abs(L.vo_transfer_alpha(float(x), 1) - L.vo_transfer_alpha_literal(float(np.float32(x) / np.float32(255.0)))) for x in xs) <= 2.5e-7
