@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed pre-roll that brings the GPU to its sustained clocks before the W warm-up frames")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline's launches (no still-camera window, no single-frame launches): what tools/prof_r3.sh profiles, so that a kernel's mean duration under rocprofv3 is the headline launch's")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather driver even at N = 1 (the like-for-like baseline of the N > 1 lines)")
     return ap.parse_args()
 
@@ -447,10 +448,12 @@ def main():
 
         elapsed, evs, run_order_ms = measure()
         # the same window with the config's ONE camera in every frame (what round 2 reported as the headline)
-        cams_now[0] = [blob] * batch
-        timed_region(batch, False)
-        still_elapsed, still_evs, _ = measure()
-        cams_now[0] = cam_list
+        still_elapsed, still_evs = None, []
+        if not args.headline_only:
+            cams_now[0] = [blob] * batch
+            timed_region(batch, False)
+            still_elapsed, still_evs, _ = measure()
+            cams_now[0] = cam_list
         n_launch_frames = batch  # frames one launch spans
         launch_ms = None
         if evs:
@@ -497,10 +500,11 @@ def main():
                 "repeats": repeats, "repeat_ms_per_step": run_order_ms, "preroll_frames": preroll_frames,
                 "device": info["device_name"], "volume_setup_s": t_volume,
                 # the same window with the config's one camera repeated in every frame of every launch
-                "still_camera": {"ms_per_step": still_elapsed / timed_frames * 1e3, "value": s_ref_still * timed_frames / still_elapsed / 1e6,
-                                 "s_ref_per_frame": s_ref_still, "s_sampled_per_frame": s_sampled_still,
-                                 **({"launch_ms": still_launch_ms,
-                                     "frac": (s_sampled_still * cfg["b_step"] + n_px * B_RAY) * batch / (still_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if still_launch_ms else {})},
+                **({"still_camera": {"ms_per_step": still_elapsed / timed_frames * 1e3, "value": s_ref_still * timed_frames / still_elapsed / 1e6,
+                                     "s_ref_per_frame": s_ref_still, "s_sampled_per_frame": s_sampled_still,
+                                     **({"launch_ms": still_launch_ms,
+                                         "frac": (s_sampled_still * cfg["b_step"] + n_px * B_RAY) * batch / (still_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if still_launch_ms else {})}}
+                   if still_elapsed is not None else {}),
             }
             if launch_ms is not None:
                 alg = alg_frame * n_launch_frames
@@ -547,7 +551,7 @@ def main():
 
         # One frame per launch -- the reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) -- on the
         # config's camera: duration of a single-frame launch and its spread, back to back on a busy GPU.
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.headline_only:
             try:
                 n1 = 100 if args.config == "c2" else 24
                 p1 = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)

@@ -83,6 +83,44 @@ DEFINE_KERNEL_C(k_fma_salu, "v_fma_f32 %0, %0, %8, %9\ns_add_u32 s20, s20, 1\nv_
 DEFINE_KERNEL_C(k_fma_cmp, "v_fma_f32 %0, %0, %8, %9\nv_cmp_lt_f32 vcc, %8, %0\nv_fma_f32 %1, %1, %8, %9\nv_cmp_lt_f32 vcc, %8, %1\nv_fma_f32 %2, %2, %8, %9\nv_cmp_lt_f32 vcc, %8, %2\n"
                          "v_fma_f32 %3, %3, %8, %9\nv_cmp_lt_f32 vcc, %8, %3\n", "vcc")
 
+DEFINE_KERNEL(k_fmac, OP2("v_fmac_f32"))
+DEFINE_KERNEL(k_add_e64, OP2("v_add_f32_e64"))
+DEFINE_KERNEL(k_max, OP2("v_max_f32"))
+DEFINE_KERNEL(k_mov, OP1("v_mov_b32"))
+DEFINE_KERNEL(k_and, OP2("v_and_b32"))
+DEFINE_KERNEL(k_cvt_f32_f16, OP1("v_cvt_f32_f16"))
+DEFINE_KERNEL(k_perm, OP3("v_perm_b32"))
+DEFINE_KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n")
+// additivity: do costs add when a cheap op and a dear one alternate?  (per PAIR)
+DEFINE_KERNEL(k_add_cos, "v_add_f32 %0, %0, %8\nv_cos_f32 %1, %1\nv_add_f32 %2, %2, %8\nv_cos_f32 %3, %3\nv_add_f32 %4, %4, %8\nv_cos_f32 %5, %5\nv_add_f32 %6, %6, %8\nv_cos_f32 %7, %7\n")
+DEFINE_KERNEL(k_add_mix, "v_add_f32 %0, %0, %8\nv_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[0,1,1]\nv_add_f32 %2, %2, %8\nv_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[0,1,1]\n"
+                         "v_add_f32 %4, %4, %8\nv_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[0,1,1]\nv_add_f32 %6, %6, %8\nv_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[0,1,1]\n")
+DEFINE_KERNEL(k_add_fract, "v_add_f32 %0, %0, %8\nv_fract_f32 %1, %1\nv_add_f32 %2, %2, %8\nv_fract_f32 %3, %3\nv_add_f32 %4, %4, %8\nv_fract_f32 %5, %5\nv_add_f32 %6, %6, %8\nv_fract_f32 %7, %7\n")
+// s_nop 0 among fmas (the compiler's hazard pads in the staged step loop): per v_fma
+DEFINE_KERNEL(k_fma_nop, "v_fma_f32 %0, %0, %8, %9\ns_nop 0\nv_fma_f32 %1, %1, %8, %9\ns_nop 0\nv_fma_f32 %2, %2, %8, %9\ns_nop 0\nv_fma_f32 %3, %3, %8, %9\ns_nop 0\n"
+                         "v_fma_f32 %4, %4, %8, %9\ns_nop 0\nv_fma_f32 %5, %5, %8, %9\ns_nop 0\nv_fma_f32 %6, %6, %8, %9\ns_nop 0\nv_fma_f32 %7, %7, %8, %9\ns_nop 0\n")
+// LDS element reads among adds (8 ds_read_u8 of one address register + wait, as the staged step does), per group of 8 reads + 8 adds
+__global__ __launch_bounds__(512) void k_lds_u8(float *out, Stamp *st, int iters) {
+    __shared__ unsigned char win[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) win[i] = (unsigned char)i;
+    __syncthreads();
+    PROLOGUE
+    unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)win + (threadIdx.x * 37u) % 4000u;
+    unsigned acc = 0;
+    for (int i = 0; i < iters; i++) {
+        unsigned l0, l1, l2, l3, l4, l5, l6, l7;
+        asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %8 offset:64\n\tds_read_u8 %3, %8 offset:65\n\t"
+                     "ds_read_u8 %4, %8 offset:512\n\tds_read_u8 %5, %8 offset:513\n\tds_read_u8 %6, %8 offset:576\n\tds_read_u8 %7, %8 offset:577\n\t"
+                     "v_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\nv_add_f32 %9, %9, %10\n"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(l4), "=&v"(l5), "=&v"(l6), "=&v"(l7) : "v"(addr), "v"(a1), "v"(c));
+        acc += l0 + l1 + l2 + l3 + l4 + l5 + l6 + l7;
+    }
+    a2 = (float)acc;
+    EPILOGUE
+}
+
 // packed ops need register pairs
 __global__ __launch_bounds__(512) void k_pk_fma(float *out, Stamp *st, int iters) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -172,12 +210,16 @@ int main(int argc, char **argv) {
         {"v_pk_fma_f32", k_pk_fma, 16}, {"v_fma_f64", k_fma_f64, 16}, {"v_fma_mix_f32", k_fma_mix, 16}, {"v_cos_f32", k_cos, 16}, {"v_exp_f32", k_exp, 16}, {"v_rcp_f32", k_rcp, 16},
         {"v_fract_f32", k_fract, 16}, {"v_cvt_flr_i32_f32", k_cvt_flr, 16}, {"v_cvt_f32_i32", k_cvt_f32_i32, 16}, {"v_cvt_f32_ubyte0", k_cvt_ub0, 16},
         {"v_min_i32", k_min_i32, 16}, {"v_add_u32", k_add_u32, 16}, {"v_lshlrev_b32", k_lshl, 16}, {"v_lshl_add_u32", k_lshl_add, 16}, {"v_add3_u32", k_add3, 16}, {"v_mad_i32_i24", k_mad_i24, 16},
-        {"v_med3_i32", k_med3_i32, 16}, {"v_fma + s_add 1:1 (per v_fma)", k_fma_salu, 16}, {"v_fma + v_cmp 1:1 (per pair)", k_fma_cmp, 8},
+        {"v_med3_i32", k_med3_i32, 16}, {"v_fmac_f32 (VOP2)", k_fmac, 16}, {"v_add_f32_e64 (VOP3)", k_add_e64, 16}, {"v_max_f32", k_max, 16}, {"v_mov_b32", k_mov, 16}, {"v_and_b32", k_and, 16},
+        {"v_cvt_f32_f16", k_cvt_f32_f16, 16}, {"v_perm_b32", k_perm, 16}, {"v_cndmask_b32", k_cndmask, 16},
+        {"v_add + v_cos 1:1 (per pair)", k_add_cos, 8}, {"v_add + v_fma_mix 1:1 (per pair)", k_add_mix, 8}, {"v_add + v_fract 1:1 (per pair)", k_add_fract, 8},
+        {"v_fma + s_nop 0 1:1 (per v_fma)", k_fma_nop, 16}, {"8 ds_read_u8 + 8 v_add + wait (per group)", k_lds_u8, 1},
+        {"v_fma + s_add 1:1 (per v_fma)", k_fma_salu, 16}, {"v_fma + v_cmp 1:1 (per pair)", k_fma_cmp, 8},
         {"cell sample body (per trip)", k_sample_body, 1}};
     const double target_ms = argc > 1 ? atof(argv[1]) : 25.0;
     printf("device: %s, %d CUs\n", prop.name, cus);
     printf("cycles per wave-instruction per SIMD = median over waves of (s_memtime ticks of the loop) / (instructions per wave x waves per SIMD); clock = ticks / s_memrealtime x 100 MHz\n");
-    printf("every cell: >= %.0f ms kernel after a 60 ms pre-roll of the v_fma loop at 8 waves per SIMD\n", target_ms);
+    printf("every cell: >= %.0f ms kernel after a 60 ms pre-roll of the v_fma loop at 8 waves per SIMD; cell = cycles (clock GHz, chip-level T lane-ops/s from the launch's wall time)\n", target_ms);
     printf("%-32s | %19s | %19s | %19s | %19s\n", "op", "w=1  cyc  (GHz)", "w=2  cyc  (GHz)", "w=4  cyc  (GHz)", "w=8  cyc  (GHz)");
     auto run = [&](kern_t k, int w, int iters, float *ms_out, double *cyc_med, double *ghz_med) {
         const int threads = 64 * 4 * w;
@@ -206,7 +248,10 @@ int main(int argc, char **argv) {
             int iters = (int)std::min(4.0e7, std::max(2000.0, 2000.0 * target_ms / std::max(ms, 1e-3f)));
             run(en.k, w, iters, &ms, &cyc, &ghz);
             const double per = cyc / ((double)iters * en.per_iter * w);
-            printf(" | %5.2f (%4.2f, %4.0fms)", per, ghz, ms);
+            // cross-check that does not use s_memtime at all: wall time of the launch (HIP events) x the clock from s_memrealtime's
+            // interval would be circular, so print the chip-level rate instead: wave-instructions x 64 lanes / wall time, in T lane-ops/s
+            const double tops = (double)cus * 4 * w * (double)iters * en.per_iter * 64.0 / (ms * 1e-3) / 1e12;
+            printf(" | %5.2f (%4.2f, %5.1fT)", per, ghz, tops);
         }
         printf("\n");
         fflush(stdout);
