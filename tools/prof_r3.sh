@@ -18,7 +18,7 @@ for shape in default driver; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/write -- $B > $o/write.log 2>&1 || { echo "write failed"; exit 1; }
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $o/sq1 -- $B > $o/sq1.log 2>&1 || { echo "sq1 failed"; exit 1; }
   rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA --output-format csv -d $o/sq2 -- $B > $o/sq2.log 2>&1 || { echo "sq2 failed"; exit 1; }
-  tail -1 $o/trace.log > $o/bench_line_under_rocprof.json
+  grep "^{" $o/trace.log | tail -1 > $o/bench_line_under_rocprof.json
   cp $o/trace/*/*kernel_stats.csv $o/kernel_stats.csv 2>/dev/null
   python3 $R/tools/pmc_summary.py $o > $o/summary.txt 2>&1
   echo "== $shape"; grep -v "pack_\|generate_\|clear_\|dist_pass\|build_" $o/summary.txt | head -40

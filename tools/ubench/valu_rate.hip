@@ -9,6 +9,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o valu_rate tools/ubench/valu_rate.hip && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -16,7 +17,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-struct Stamp { unsigned long long cyc, rt; };
+struct Stamp { unsigned long long cyc, rt, rt0, rt1; unsigned hwid, xcc; };
 
 #define PROLOGUE                                                                                  \
     float a0 = threadIdx.x * 0.001f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f;                 \
@@ -29,7 +30,8 @@ struct Stamp { unsigned long long cyc, rt; };
 #define EPILOGUE                                                                                  \
     const unsigned long long m1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;           \
-    if ((threadIdx.x & 63) == 0) { Stamp s; s.cyc = m1 - m0; s.rt = r1 - r0; st[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s; }
+    if ((threadIdx.x & 63) == 0) { Stamp s; s.cyc = m1 - m0; s.rt = r1 - r0; s.rt0 = r0; s.rt1 = r1; s.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+        s.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); st[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s; }
 
 // 8 independent chains, 16 instructions per loop iteration (the loop's s_add / s_cmp / s_cbranch are 3 scalar per 16 vector)
 #define DEFINE_KERNEL(NAME, ASM8) DEFINE_KERNEL_C(NAME, ASM8, "memory")
@@ -92,6 +94,18 @@ DEFINE_KERNEL(k_cvt_f32_f16, OP1("v_cvt_f32_f16"))
 DEFINE_KERNEL(k_perm, OP3("v_perm_b32"))
 DEFINE_KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
                          "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n")
+// v_cndmask variants: mask in VCC written once by a VALU compare before the stream; compare + select pairs; mask in an SGPR pair
+DEFINE_KERNEL_C(k_cndmask_vcc_set, "v_cmp_gt_f32 vcc, %8, %9\ns_nop 4\n"
+                                   "v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+                                   "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n", "vcc")
+DEFINE_KERNEL_C(k_cmp_cndmask, "v_cmp_gt_f32 vcc, %8, %0\nv_cndmask_b32 %0, %0, %9, vcc\nv_cmp_gt_f32 vcc, %8, %1\nv_cndmask_b32 %1, %1, %9, vcc\n"
+                               "v_cmp_gt_f32 vcc, %8, %2\nv_cndmask_b32 %2, %2, %9, vcc\nv_cmp_gt_f32 vcc, %8, %3\nv_cndmask_b32 %3, %3, %9, vcc\n", "vcc")
+DEFINE_KERNEL_C(k_cndmask_sgpr, "v_cndmask_b32_e64 %0, %0, %8, s[20:21]\nv_cndmask_b32_e64 %1, %1, %8, s[20:21]\nv_cndmask_b32_e64 %2, %2, %8, s[20:21]\nv_cndmask_b32_e64 %3, %3, %8, s[20:21]\n"
+                                "v_cndmask_b32_e64 %4, %4, %8, s[20:21]\nv_cndmask_b32_e64 %5, %5, %8, s[20:21]\nv_cndmask_b32_e64 %6, %6, %8, s[20:21]\nv_cndmask_b32_e64 %7, %7, %8, s[20:21]\n", "s20", "s21")
+DEFINE_KERNEL(k_bfi, OP3("v_bfi_b32"))
+DEFINE_KERNEL(k_xor, OP2("v_xor_b32"))
+DEFINE_KERNEL(k_floor, OP1("v_floor_f32"))
+DEFINE_KERNEL(k_rndne, OP1("v_rndne_f32"))
 // additivity: do costs add when a cheap op and a dear one alternate?  (per PAIR)
 DEFINE_KERNEL(k_add_cos, "v_add_f32 %0, %0, %8\nv_cos_f32 %1, %1\nv_add_f32 %2, %2, %8\nv_cos_f32 %3, %3\nv_add_f32 %4, %4, %8\nv_cos_f32 %5, %5\nv_add_f32 %6, %6, %8\nv_cos_f32 %7, %7\n")
 DEFINE_KERNEL(k_add_mix, "v_add_f32 %0, %0, %8\nv_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[0,1,1]\nv_add_f32 %2, %2, %8\nv_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[0,1,1]\n"
@@ -211,16 +225,21 @@ int main(int argc, char **argv) {
         {"v_fract_f32", k_fract, 16}, {"v_cvt_flr_i32_f32", k_cvt_flr, 16}, {"v_cvt_f32_i32", k_cvt_f32_i32, 16}, {"v_cvt_f32_ubyte0", k_cvt_ub0, 16},
         {"v_min_i32", k_min_i32, 16}, {"v_add_u32", k_add_u32, 16}, {"v_lshlrev_b32", k_lshl, 16}, {"v_lshl_add_u32", k_lshl_add, 16}, {"v_add3_u32", k_add3, 16}, {"v_mad_i32_i24", k_mad_i24, 16},
         {"v_med3_i32", k_med3_i32, 16}, {"v_fmac_f32 (VOP2)", k_fmac, 16}, {"v_add_f32_e64 (VOP3)", k_add_e64, 16}, {"v_max_f32", k_max, 16}, {"v_mov_b32", k_mov, 16}, {"v_and_b32", k_and, 16},
-        {"v_cvt_f32_f16", k_cvt_f32_f16, 16}, {"v_perm_b32", k_perm, 16}, {"v_cndmask_b32", k_cndmask, 16},
+        {"v_cvt_f32_f16", k_cvt_f32_f16, 16}, {"v_perm_b32", k_perm, 16}, {"v_cndmask_b32 (vcc never written)", k_cndmask, 16},
+        {"v_cndmask_b32 (vcc from v_cmp, per 8+1)", k_cndmask_vcc_set, 2}, {"v_cmp + v_cndmask (per pair)", k_cmp_cndmask, 8}, {"v_cndmask_b32_e64 (SGPR pair)", k_cndmask_sgpr, 16},
+        {"v_bfi_b32", k_bfi, 16}, {"v_xor_b32", k_xor, 16}, {"v_floor_f32", k_floor, 16}, {"v_rndne_f32", k_rndne, 16},
         {"v_add + v_cos 1:1 (per pair)", k_add_cos, 8}, {"v_add + v_fma_mix 1:1 (per pair)", k_add_mix, 8}, {"v_add + v_fract 1:1 (per pair)", k_add_fract, 8},
         {"v_fma + s_nop 0 1:1 (per v_fma)", k_fma_nop, 16}, {"8 ds_read_u8 + 8 v_add + wait (per group)", k_lds_u8, 1},
         {"v_fma + s_add 1:1 (per v_fma)", k_fma_salu, 16}, {"v_fma + v_cmp 1:1 (per pair)", k_fma_cmp, 8},
         {"cell sample body (per trip)", k_sample_body, 1}};
     const double target_ms = argc > 1 ? atof(argv[1]) : 25.0;
     printf("device: %s, %d CUs\n", prop.name, cus);
-    printf("cycles per wave-instruction per SIMD = median over waves of (s_memtime ticks of the loop) / (instructions per wave x waves per SIMD); clock = ticks / s_memrealtime x 100 MHz\n");
+    printf("cell = cycles per wave-instruction on ONE SIMD, median over the SIMDs: (first start .. last end of the waves that ran on it, s_memrealtime x the wave's own clock) / (their wave-instructions);\n"
+           "       `Nw` = waves that actually ran on the median SIMD (HW_ID); (clock GHz = s_memtime / s_memrealtime x 100 MHz; chip-level T lane-ops/s from the launch's wall time)\n");
     printf("every cell: >= %.0f ms kernel after a 60 ms pre-roll of the v_fma loop at 8 waves per SIMD; cell = cycles (clock GHz, chip-level T lane-ops/s from the launch's wall time)\n", target_ms);
-    printf("%-32s | %19s | %19s | %19s | %19s\n", "op", "w=1  cyc  (GHz)", "w=2  cyc  (GHz)", "w=4  cyc  (GHz)", "w=8  cyc  (GHz)");
+    printf("%-32s | %24s | %24s | %24s | %24s\n", "op", "4 waves/CU", "8 waves/CU", "16 waves/CU", "32 waves/CU");
+    double simd_per = 0, waves_per_simd = 0, span_over_wall = 0;  // filled by run(): per-SIMD accounting by where the waves actually ran
+    int per_iter_now = 16;
     auto run = [&](kern_t k, int w, int iters, float *ms_out, double *cyc_med, double *ghz_med) {
         const int threads = 64 * 4 * w;
         dim3 block(threads > 512 ? 512 : threads);
@@ -238,12 +257,41 @@ int main(int argc, char **argv) {
         for (auto &s : h) { cy.push_back((double)s.cyc); gz.push_back(s.rt ? (double)s.cyc / (double)s.rt * 0.1 : 0.0); }
         std::sort(cy.begin(), cy.end()); std::sort(gz.begin(), gz.end());
         *cyc_med = cy[cy.size() / 2]; *ghz_med = gz[gz.size() / 2];
+        // Where did the waves run?  Key = (XCC, SE, SH, CU, SIMD) from HW_ID / XCC_ID.  A SIMD's cost per instruction = the shader cycles
+        // between its first wave's start and its last wave's end / the wave-instructions its waves issued -- whatever the dispatcher's
+        // placement was (it is NOT "w waves on every SIMD": a launch of exactly the chip's capacity does not land evenly).
+        struct Acc { unsigned long long t0 = ~0ull, t1 = 0; int n = 0; };
+        std::map<unsigned long long, Acc> by;
+        unsigned long long g0 = ~0ull, g1 = 0;
+        for (auto &s : h) {
+            const unsigned long long key = ((unsigned long long)(s.xcc & 0xf) << 32) | (s.hwid & 0xfff0u & ~0xc0u);  // drop wave_id[3:0] and pipe_id[7:6]
+            Acc &a = by[key];
+            a.t0 = std::min(a.t0, s.rt0); a.t1 = std::max(a.t1, s.rt1); a.n++;
+            g0 = std::min(g0, s.rt0); g1 = std::max(g1, s.rt1);
+        }
+        std::vector<double> per, nw;
+        for (auto &kv : by) {
+            const double span_cyc = (double)(kv.second.t1 - kv.second.t0) * 10.0 * (*ghz_med);  // realtime ticks are 10 ns
+            per.push_back(span_cyc / ((double)kv.second.n * iters * per_iter_now));
+            nw.push_back(kv.second.n);
+        }
+        std::sort(per.begin(), per.end()); std::sort(nw.begin(), nw.end());
+        simd_per = per[per.size() / 2]; waves_per_simd = nw[nw.size() / 2];
+        span_over_wall = (double)(g1 - g0) * 1e-5 / *ms_out;
+        if (getenv("UB_VERBOSE")) printf("\n   [w=%d: %zu SIMDs used, waves per SIMD min/med/max %g/%g/%g, first start to last end %.2f ms of %.2f ms wall]", w, by.size(), nw.front(), waves_per_simd, nw.back(), (double)(g1 - g0) * 1e-5, *ms_out);
     };
     for (auto &en : ks) {
+        if (argc > 2) {  // only the rows whose name contains one of the comma-separated patterns
+            bool hit = false;
+            std::string pats(argv[2]);
+            for (size_t a = 0; a <= pats.size();) { size_t b = pats.find(',', a); if (b == std::string::npos) b = pats.size(); if (b > a && std::string(en.name).find(pats.substr(a, b - a)) != std::string::npos) hit = true; a = b + 1; }
+            if (!hit) continue;
+        }
         printf("%-32s", en.name);
         for (int w : {1, 2, 4, 8}) {
             float ms; double cyc, ghz;
             run(k_fma, 8, 400000, &ms, &cyc, &ghz);  // pre-roll (~60 ms)
+            per_iter_now = en.per_iter;
             run(en.k, w, 2000, &ms, &cyc, &ghz);     // calibrate
             int iters = (int)std::min(4.0e7, std::max(2000.0, 2000.0 * target_ms / std::max(ms, 1e-3f)));
             run(en.k, w, iters, &ms, &cyc, &ghz);
@@ -251,7 +299,8 @@ int main(int argc, char **argv) {
             // cross-check that does not use s_memtime at all: wall time of the launch (HIP events) x the clock from s_memrealtime's
             // interval would be circular, so print the chip-level rate instead: wave-instructions x 64 lanes / wall time, in T lane-ops/s
             const double tops = (double)cus * 4 * w * (double)iters * en.per_iter * 64.0 / (ms * 1e-3) / 1e12;
-            printf(" | %5.2f (%4.2f, %5.1fT)", per, ghz, tops);
+            (void)per;
+            printf(" | %5.2f %3.0fw (%4.2f, %5.1fT)", simd_per, waves_per_simd, ghz, tops);
         }
         printf("\n");
         fflush(stdout);

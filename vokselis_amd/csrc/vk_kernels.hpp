@@ -1545,9 +1545,21 @@ __device__ __forceinline__ float sin_spec(float h) {
     cp = fma_k(cp, r2, -1.38888888888741095749e-03);
     cp = fma_k(cp, r2, 4.16666666666666019037e-02);
     const double cs = fma(r2 * r2, cp, fma(-0.5, r2, 1.0));
-    const int q = (int)k & 3;  // |k| < 2^31 for every argument the hash makes
-    const double v = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
-    return (float)v;
+    // Quadrant (|k| < 2^31 for every argument the hash makes): q = k & 3 -> sn, cs, -sn, -cs.  Written on the bit patterns -- odd q takes
+    // the cosine series (v_bfi_b32 on both halves), bit 1 of q flips the sign bit -- because the compiler lowers the four-way select of
+    // doubles to two nested exec-mask branches per sine (6 scalar instructions, 3 compares, 2 v_cndmask through VCC: about a third of a
+    // sine's issue cycles by profiles/r03_ubench_valu_issue_rate.txt, 24 sines per step).  The same value bit for bit: a negated double
+    // differs in its sign bit only.
+    const uint32_t qi = (uint32_t)(int)k;
+    union { double d; uint32_t u[2]; } S, C, R;
+    S.d = sn; C.d = cs;
+    const uint32_t odd = 0u - (qi & 1u);  // all ones: the cosine series
+    uint32_t lo, hi;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(odd), "v"(C.u[0]), "v"(S.u[0]));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(odd), "v"(C.u[1]), "v"(S.u[1]));
+    R.u[0] = lo;
+    R.u[1] = hi ^ ((qi << 30) & 0x80000000u);
+    return (float)R.d;
 }
 __device__ __forceinline__ float xor_fract(float x) { return x - floorf(x); }
 __device__ __forceinline__ float xor_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }

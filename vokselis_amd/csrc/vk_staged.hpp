@@ -37,6 +37,7 @@ struct StagedDesc {
     uint32_t nbm[3];               // per copy: bricks along its MID axis
     uint32_t cap_bytes;            // LDS window capacity = dynamic LDS of the launch
     uint32_t slab_cells;           // a round is a slab of at most this many cells along the wave's major axis
+    uint32_t row_pad;              // 1: window rows of an even number of pieces carry one more (an odd row pitch, in pieces, spreads the rows of a wave over the LDS banks)
 };
 
 // floor(q / d) = umulhi(q, kMagic[d]) for q * d < 2^32, d in [2, 64]
@@ -88,6 +89,13 @@ __device__ __forceinline__ void wave_minmax4(int a, int b, int c, int d, int &ra
                  : "=s"(ra), "=s"(rb), "=s"(rc), "=s"(rd), "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     ra = __builtin_amdgcn_readfirstlane(ra); rb = __builtin_amdgcn_readfirstlane(rb);  // wave-uniform, see wave_min_i32
     rc = __builtin_amdgcn_readfirstlane(rc); rd = __builtin_amdgcn_readfirstlane(rd);
+}
+
+// mask bit set ? a : b, the lane mask in a scalar register pair (v_cndmask_b32_e64)
+__device__ __forceinline__ int select_i32(unsigned long long mask, int a, int b) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
 }
 
 // Dense voxels -> one staged copy.  One thread per 16-byte piece, pieces enumerated in storage order.
@@ -290,11 +298,18 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         const int kMl = cvt_floor_i32(fminf(uM, eM) * 64.0f), kMh = cvt_floor_i32(fmaxf(uM, eM) * 64.0f);
         const int kFl = cvt_floor_i32(fminf(uF, eF) * 64.0f), kFh = cvt_floor_i32(fmaxf(uF, eF) * 64.0f);
         int bMl, bMh, bFl, bFh;
-        wave_minmax4(inslab ? kMl : 0x7fffffff, inslab ? kMh : (int)0x80000000, inslab ? kFl : 0x7fffffff, inslab ? kFh : (int)0x80000000, bMl, bMh, bFl, bFh);
+        // (the four selects through an SGPR-pair mask: four v_cndmask in a row through VCC, as the compiler writes them, cost ~16 issue
+        // cycles each -- profiles/r03_ubench_valu_issue_rate.txt -- against 4 in this form)
+        const unsigned long long in_mask = __ballot(inslab);
+        wave_minmax4(select_i32(in_mask, kMl, 0x7fffffff), select_i32(in_mask, kMh, (int)0x80000000), select_i32(in_mask, kFl, 0x7fffffff), select_i32(in_mask, kFh, (int)0x80000000), bMl, bMh, bFl, bFh);
         bMl -= 2; bMh += 3; bFl -= 2; bFh += 3;
         const int ilM = min(max((bMl >> 6) + kStagePad, 0), nvm1[M]), ihM = min(max((bMh >> 6) + kStagePad + 1, 0), nvm1[M]);  // + 1: the upper tap
         const int ilF = min(max((bFl >> 6) + kStagePad, 0), nvm1[F]), ihF = min(max((bFh >> 6) + kStagePad + 1, 0), nvm1[F]);
-        const uint32_t pf0 = (uint32_t)ilF >> VSH, Efp = ((uint32_t)ihF >> VSH) - pf0 + 1u, Em = (uint32_t)(ihM - ilM) + 1u;
+        const uint32_t pf0 = (uint32_t)ilF >> VSH, Efn = ((uint32_t)ihF >> VSH) - pf0 + 1u, Em = (uint32_t)(ihM - ilM) + 1u;
+        // row pitch in pieces: the pieces the rays need, plus one when that makes the pitch odd (row_pad): rows of 4 pieces (64 B) put every
+        // fourth window row -- i.e. every second pixel row of the wave -- on the same LDS banks.  The extra piece is fetched like the others
+        // (the DMA writes 64 consecutive pieces per instruction: a hole cannot be skipped) and never read.
+        const uint32_t Efp = (D.row_pad && !(Efn & 1u) && Efn < 64u) ? Efn + 1u : Efn;
         // the thickest slab whose box fits the window (scalar)
         int ilS;
         uint32_t Es;
@@ -322,7 +337,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     const uint32_t m = Efp == 1u ? q : __umulhi(q, mgF);
                     const uint32_t f = q - m * Efp;
                     const uint32_t mm = (uint32_t)ilM + m;
-                    const uint32_t voff = ((pf0 + f + npf * (mm >> 3)) << 10) | ((mm & 7u) << 4);
+                    const uint32_t voff = ((pf0 + min(f, Efn - 1u) + npf * (mm >> 3)) << 10) | ((mm & 7u) << 4);  // (f == Efn: the pad piece repeats the row's last one)
                     // global_load_lds_dwordx4 with the slice's base in a scalar pair and the lane's 32-bit offset: no vector
                     // arithmetic per load (the builtin only takes a 64-bit per-lane address: one v_lshl_add_u64 each).  The
                     // base moves by 128 bytes per slice inside a layer of bricks and by the rest of the layer at a brick
