@@ -21,18 +21,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # cycles per wave-instruction per SIMD at 8 waves per SIMD (profiles/r03_ubench_valu_issue_rate.txt)
 COST = {
-    "vop2_fast": 1.04,   # v_add_f32 v_sub_f32 v_mul_f32 v_add_u32 v_sub_u32 v_fmac_f32 (32-bit encodings, full rate)
-    "fma": 1.33,         # v_fma_f32 and the other full-rate VOP3 f32 ops
-    "half": 1.69,        # v_min/max_f32, v_fract, v_cvt_*, v_lshlrev, v_and/or/xor, v_cndmask, v_mov
-    "vop3_int": 2.24,    # v_lshl_add_u32 v_add3_u32 v_mad_i32_i24 v_med3 v_perm v_alignbit v_bfe v_and_or v_lshl_or
-    "mix": 2.24,         # v_fma_mix_f32
-    "pk": 2.27,          # v_pk_*_f32
-    "trans": 2.00,       # v_cos v_sin v_exp v_log v_rcp v_rsq v_sqrt
-    "f64": 1.92,         # v_fma_f64 v_mul_f64 v_add_f64 (v_fma_f64 measured)
-    "cmp": 1.40,         # v_cmp_* (pair with an fma measured 2.73)
-    "dpp": 2.24,
-    "salu": 1.33,        # one scalar instruction beside a vector stream (v_fma + s_add pairs: 2.66 per pair)
-    "lds": 2.0, "vmem": 4.0, "smem": 1.33, "wait": 0.0, "branch": 1.33, "other": 1.7,
+    "vop2_fast": 2.0,    # v_add/sub/mul/fmac_f32, v_add_u32, v_mov, v_and/xor (full rate)
+    "fma": 2.0,          # v_fma_f32 (full rate; VOP3 encoding makes no difference)
+    "half": 4.0,         # v_min/max_f32, v_fract/floor, every v_cvt_*, shifts, v_min_i32, v_cndmask_b32_e64
+    "vop3_int": 4.0,     # v_lshl_add_u32 v_add3_u32 v_mad_i32_i24 v_med3 v_perm v_bfi
+    "mix": 4.0,          # v_fma_mix_f32
+    "pk": 4.0,           # v_pk_*_f32 (two results)
+    "trans": 8.0,        # v_cos v_sin v_exp v_log v_rcp v_rsq v_sqrt
+    "f64": 4.0,          # v_fma_f64 (measured); other f64 ops priced alike
+    "cmp": 2.5,          # v_cmp_* (pair with an fma measured 4.7)
+    "dpp": 4.0,
+    "salu": 2.4,         # a scalar instruction beside a vector stream (v_fma + s_add pairs: 4.8 per pair); overlaps long vector ops
+    "lds": 4.0, "vmem": 4.0, "smem": 2.4, "wait": 0.5, "branch": 2.4, "other": 3.0,
 }
 
 
@@ -67,7 +67,7 @@ def classify(op: str) -> str:
         return "vop2_fast"
     if re.match(r"v_(fma|mad)_f32", op) or re.match(r"v_(add|sub|mul)_f32_e64", op):
         return "fma"
-    if re.match(r"v_(lshl_add|add3|mad_i32_i24|mad_u32_u24|med3|perm|alignbit|alignbyte|bfe|and_or|lshl_or|add_lshl|or3|xad|mad_u64|mul_lo|mul_hi|lshl_add_u64)", op):
+    if re.match(r"v_(lshl_add|add3|mad_i32_i24|mad_u32_u24|med3|perm|alignbit|alignbyte|bfe|bfi|and_or|lshl_or|add_lshl|or3|xad|mad_u64|mul_lo|mul_hi|lshl_add_u64)", op):
         return "vop3_int"
     return "half"
 
