@@ -581,6 +581,10 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     if (COUNT) { n_iter += 4; if (wave_leader()) w_inner++; }
                 }
                 if (t < tstop2) {
+                    // (the empty asm keeps this an exec-masked region: if-converted, the two steps are computed for every lane and
+                    // then selected by FOUR v_cndmask through VCC in a row, ~16 issue cycles each -- profiles/r03_ubench_valu_issue_rate.txt --
+                    // twice the cost of a whole four-step walk iteration)
+                    asm volatile("" : "+v"(t));
                     px = px + sx; py = py + sy; pz = pz + sz;
                     t = t + dt;
                     px = px + sx; py = py + sy; pz = pz + sz;
