@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     with socket.socket() as s:
@@ -92,3 +94,53 @@ def test_gloo_world2_tile_gather(W, H, ts):
     got = sorted(q.get(timeout=5) for _ in range(3))
     assert [g[0] for g in got] == [0, 1, 2]
     assert all(g[2] for g in got), got  # bit-identical to the single-process oracle frames
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...`, typed exactly like the N = 1 line (no torchrun, no WORLD_SIZE): bench.py must start its
+    two ranks itself, as a CHILD torch.distributed.run, before anything touches a GPU.  This container has none, so each rank
+    must then stop with the no-GPU message (there is no CPU fallback) and the parent must leave with the child's non-zero code --
+    which proves the launch path end to end without a device.  (On the GPU box the same line runs to its JSON:
+    tests/test_parity_gpu.py::test_bench_multi_rank_flow_rehearsal[plain].)"""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu suite")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X: no GPU visible") >= 2, r.stderr[-2000:]  # one per rank: the ranks did start
+    assert "must be launched with torch.distributed.run" not in r.stderr
+
+
+def test_bench_window_rule():
+    """One contiguous timed window of M = K * ceil(max(100, 4 launches) / K) frames in launches of equal size (>= 100
+    timed frames; a gather pipeline only fills over several launches): the arithmetic bench.py applies at every N."""
+    for K, batch0, want_M in ((20, 64, 260), (256, 64, 256), (24, 64, 264), (20, 4, 100), (7, 256, 1029), (1000, 64, 1000)):
+        timed = K * -(-max(100, 4 * batch0) // K)
+        n_launch = max(1, -(-timed // batch0))
+        batch = -(-timed // n_launch)
+        assert timed == want_M and timed % K == 0 and timed >= 100 and timed >= 4 * batch0
+        assert n_launch >= 4 and batch * n_launch >= timed and batch <= batch0 and batch * n_launch - timed < n_launch
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "timed_frames = K * -(-max(100, 4 * batch) // K)" in src and "batch = -(-timed_frames // n_launch)" in src
+
+
+def test_fake_rccl_builds_and_exports_the_bound_symbols():
+    """The single-process stand-in for RCCL the gpu suite binds through VK_RCCL_LIB (tests/fake_rccl.cpp) builds here and
+    exports the nine entry points vk_api.hip resolves (no call without a GPU)."""
+    import ctypes as C
+
+    import __graft_entry__ as g
+
+    lib = C.CDLL(g.build_fake_rccl())
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+                 "ncclGetErrorString", "fake_rccl_stats", "fake_rccl_unmatched"):
+        assert getattr(lib, name) is not None
+    src = open(os.path.join(ROOT, "vokselis_amd", "csrc", "vk_api.hip")).read()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
+        assert 'sym("%s")' % name in src, name
