@@ -44,6 +44,17 @@ sys.path.insert(0, ROOT)
 TILE = 64
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock (same guide); an f32 full-rate wave64 instruction holds a SIMD for 2 cycles,
+                               # a half-rate one (f64 fma, cvt, fract, min/max, v_fma_mix, 3-operand integer ops) for 4, a transcendental for 8
+                               # (profiles/r03_ubench_valu_issue_rate.txt)
+F64_LANE_OPS_PEAK = SIMDS * 16 * CLOCK_HZ  # 39.3 T f64 lane-operations/s = 78.6 TFLOP/s of fma
+
+
+def valu_floor_frac(steps, valu_per_step, mean_cost, ms):
+    """VALU pipe occupancy a kernel cannot be below: (steps / 64 full waves) x vector instructions per step x their mean issue cost, over
+    the SIMD cycles of the launch at the maximum clock.  Partly empty waves and a lower sustained clock both raise the true figure
+    (PMC-based: profiles/r03_utilisation.txt)."""
+    return steps / 64.0 * valu_per_step * mean_cost / (SIMDS * CLOCK_HZ * ms * 1e-3)
 B_RAY = 8                  # rgba16f per ray (SURVEY 8d)
 
 # BASELINE.json configs that fit one GPU (SURVEY 8d): volume edge, format, image, seed, bytes per step
@@ -538,6 +549,15 @@ def main():
                         out["roofline"]["compulsory_GBps"] = (cfg["n"] ** 3 * (1 if cfg["fmt"] == "u8" else 2) + n_px * B_RAY * n_launch_frames) / (launch_ms * 1e-3) / 1e9
                     except Exception:
                         pass
+                # the VALU side of the same kernel (it is bound by instruction issue, not by bytes): occupancy of the vector pipe and of the
+                # issue slots from the PMC passes of this launch shape, priced with the measured issue classes
+                try:
+                    uj = json.load(open(os.path.join(ROOT, "profiles", "r03_utilisation.json")))
+                    ent = uj.get({"c2": "default", "c4": "c4", "c5": "c5"}[args.config])
+                    if ent and not args.no_skip and args.layout == "auto":
+                        out["roofline"]["issue"] = {k: ent[k] for k in ("valu_pipe_occupancy", "issue_slot_occupancy", "cycles_per_valu_instruction", "hot_loop_mean_issue_cycles", "source")}
+                except Exception:
+                    pass
             else:
                 # N > 1 (and --force-dist): march, gather and un-tile of different batches overlap on every rank, so no single
                 # kernel duration describes a step; the figure here is the whole job's algorithmic bytes over the wall time
@@ -674,7 +694,11 @@ def main():
                     ms = time_launches(cx, lambda: pc.record(cx), it)
                     gb = (ss * 16 + 1280 * 720 * B_RAY) / (ms * 1e-3) / 1e9
                     extras["xor_compute_nearest_720p"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
-                                                          "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS}
+                                                          "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
+                                                          # the byte roofline is the wrong yardstick for a 76-instruction step on a 16-byte record: its VALU side
+                                                          "valu_per_step": 76, "valu_mean_issue_cycles": 3.07, "valu_frac_floor": valu_floor_frac(sr, 76, 3.07, ms),
+                                                          "valu_frac_pmc": "0.37 (profiles/r03_utilisation.txt: 2.5 waves per SIMD on average -- the 720p frame is one partial round of waves "
+                                                                           "whose longest rays, 293 steps x ~90 instructions x ~6 cycles for a lone wave, set the frame time)"}
                     # the same frame eight per launch: what the kernel does once the machine is full (a single 720p frame
                     # is 14 400 waves, less than two rounds of the 8192 wave slots)
                     xfr = torch.empty((8, 720, 1280, 4), dtype=torch.float16, device="cuda")
@@ -700,9 +724,15 @@ def main():
                     sr, _ = cp.step_counts()
                     pp = V.RaycastPipeline(V.MODE_PROCEDURAL)
                     ms = time_launches(cp, lambda: pp.record(cp), 5, warm=1)
+                    # per step (static count of the loop, tools/isa_hist.py): 552 f64 instructions (24 sines x 23: Cody-Waite reduction, two
+                    # Horner series, quadrant pick), 400 f32 / integer ones.  Fraction of the f64 vector peak = f64 lane-operations per
+                    # second / (1024 SIMDs x 16 lanes x 2.4 GHz); bound "valu" ("flops/step vs VALU peak, not HBM").
+                    f64_rate = 552.0 * sr / (ms * 1e-3)
                     extras["c3_procedural_1080p"] = {"launch_ms": ms, "s_ref": sr, "Mray_steps_per_s": sr / ms / 1e3,
-                                                     "Gsines_per_s": 24 * sr / ms / 1e6, "f64_ops_per_step_est": 24 * 45,
-                                                     "f32_ops_per_step_est": 200, "volume_bytes_per_step": 0}
+                                                     "Gsines_per_s": 24 * sr / ms / 1e6, "f64_instructions_per_step": 552, "other_valu_per_step": 400,
+                                                     "bound": "valu (f64)", "f64_T_lane_ops_per_s": f64_rate / 1e12, "f64_frac_of_vector_peak": f64_rate / F64_LANE_OPS_PEAK,
+                                                     "valu_frac_floor": valu_floor_frac(sr, 952, 3.77, ms),
+                                                     "valu_frac_pmc": "0.80 (profiles/r03_utilisation.txt; 112 VGPRs: 4 waves per SIMD)", "volume_bytes_per_step": 0}
                 finally:
                     cp.close()
             except Exception as e:

@@ -66,7 +66,9 @@ def loop_mix(regex, want_valu):
 
 
 def main():
-    roots = sys.argv[1:]
+    roots = [a for a in sys.argv[1:] if not a.startswith("--json=")]
+    jpath = next((a[7:] for a in sys.argv[1:] if a.startswith("--json=")), None)
+    jout = {}
     print(__doc__.split("  python tools")[0].strip())
     print()
     for title, sub, frag, regex, want in CASES:
@@ -81,6 +83,9 @@ def main():
         valu = c["SQ_INSTS_VALU"] / 1024.0
         others = sum(c.get(k, 0.0) for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")) / 1024.0
         lv, mean, label = loop_mix(regex, want)
+        jout[sub] = {"case": title, "kernel": frag, "kernel_ms_rocprofv3": (ns or 0) / 1e6, "cycles_per_valu_instruction": cyc / valu, "hot_loop_mean_issue_cycles": mean,
+                     "valu_pipe_occupancy": valu * mean / cyc, "issue_slot_occupancy": (valu + others) * 2.4 / cyc,
+                     "source": "profiles/r03_utilisation.txt (tools/utilisation.py over the PMC passes of tools/prof_r3.sh / prof_r3_kernels.sh; issue classes: profiles/r03_ubench_valu_issue_rate.txt)"}
         print("== %s" % title)
         print("   kernel %s: %.4f ms mean over %d launches (rocprofv3 --kernel-trace), %.2f GHz by GRBM_GUI_ACTIVE / 8 / time" % (frag, (ns or 0) / 1e6, calls, cyc / (ns or 1)))
         print("   cycles per SIMD %.3e | VALU instructions per SIMD %.3e -> %.2f cycles per VALU instruction" % (cyc, valu, cyc / valu))
@@ -94,6 +99,9 @@ def main():
         if c.get("SQ_LDS_IDX_ACTIVE"):
             print("   LDS: bank-conflict cycles / active cycles %.2f; LDS instructions per CU-cycle %.3f" % (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], c.get("SQ_INSTS_LDS", 0) / 256.0 / cyc))
         print()
+    if jpath:
+        import json
+        json.dump(jout, open(jpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,7 @@ struct StagedDesc {
     uint32_t nbm[3];               // per copy: bricks along its MID axis
     uint32_t cap_bytes;            // LDS window capacity = dynamic LDS of the launch
     uint32_t slab_cells;           // a round is a slab of at most this many cells along the wave's major axis
+    uint32_t grow_every;           // the slab search tries one cell above the last fit every grow_every-th round (>= 1)
     uint32_t row_pad;              // 1: window rows of an even number of pieces carry one more (an odd row pitch, in pieces, spreads the rows of a wave over the LDS banks)
 };
 
@@ -278,6 +279,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     const float ratM = (s[M] * fn[M]) * inv, ratF = (s[F] * fn[F]) * inv;  // lateral cells per cell of S
 
     int Tprev = T0, sig_next = 0;
+    uint32_t round_no = 0;
     bool have_sig = false;
     const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
     for (;;) {
@@ -289,7 +291,10 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
         // after a marched slab every live ray has left it (or was ahead of it), so the cell behind its far plane is a valid
         // start without looking (if the rearmost ray is further on, the slab only holds a few unused cells).
         const int sig = have_sig ? sig_next : (dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000));
-        int T = min(T0, Tprev + 1);  // the box changes slowly from round to round: the search starts one above the last fit
+        // The box changes slowly from round to round: the search starts at the last fit, and one above it only every `grow_every`-th round
+        // (tried every round, the thicker slab fails most of the time -- ~25 scalar instructions of a round's ~240, on a kernel at its
+        // issue-slot limit).  Any T is exact: a thinner slab only means more rounds.
+        int T = min(T0, Tprev + ((round_no++ % D.grow_every) == 0u ? 1 : 0));
         int clo = dir_up ? sig : sig - T + 1;
         const bool inslab = live && (uint32_t)(iS - clo) < (uint32_t)T;
         // lateral bounds of the rays in the slab: from here to the slab's far plane
