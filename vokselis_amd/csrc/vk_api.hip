@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace vk;
@@ -1462,6 +1463,43 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     std::vector<unsigned char> key(144 + 32);
     std::memcpy(key.data() + 144, kk, 32);
     std::vector<uint32_t> actives(n_frames, 0u);
+    // Frames whose camera differs from the frame before them each need an order of their own: ~10 us of host arithmetic apiece (hull test of 510
+    // tiles, estimate rays, sort).  One GPU hides that behind its 69 us per frame; a rank of 8 marches its share of a frame in ~9 us, and a
+    // stream of distinct cameras would leave it waiting for its own host.  The frames are independent, so they are cut over a few threads
+    // (nothing below writes shared state: every frame owns its slice of the staging block).
+    std::vector<uint32_t> own;  // frames that compute their order (the others copy the frame before them)
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const float *c = cams + 36 * f;
+        if (f > 0 && std::memcmp(c, c - 36, 144) == 0) continue;
+        if (f == 0) {
+            std::memcpy(key.data(), c, 144);
+            if (key == ctx->batch_key && order.size() == n_tiles) {
+                std::memcpy(h_order, order.data(), n_tiles * sizeof(uint32_t));
+                std::memcpy(h_pos, pos.data(), n_tiles * sizeof(uint32_t));
+                actives[0] = ctx->batch_n_active;
+                continue;
+            }
+        }
+        own.push_back(f);
+    }
+    {
+        auto work = [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                const uint32_t f = own[k];
+                compute_tile_order_raw(ctx, cams + 36 * f, geo_mode, 0, 0, ctx->width, ctx->height, ts, h_order + (size_t)f * n_tiles, h_pos + (size_t)f * n_tiles, actives[f], G);
+            }
+        };
+        const size_t n_own = own.size();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t n_thr = n_own >= 24 ? std::min<size_t>({4, hw, n_own / 8}) : 1;
+        if (n_thr <= 1) work(0, n_own);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t i = 1; i < n_thr; i++) pool.emplace_back(work, n_own * i / n_thr, n_own * (i + 1) / n_thr);
+            work(0, n_own / n_thr);
+            for (auto &t : pool) t.join();
+        }
+    }
     for (uint32_t f = 0; f < n_frames; f++) {
         const float *c = cams + 36 * f;
         uint32_t *fo = h_order + (size_t)f * n_tiles, *fp = h_pos + (size_t)f * n_tiles;
@@ -1469,15 +1507,6 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
             std::memcpy(fo, fo - n_tiles, n_tiles * sizeof(uint32_t));
             std::memcpy(fp, fp - n_tiles, n_tiles * sizeof(uint32_t));
             actives[f] = actives[f - 1];
-        } else {
-            std::memcpy(key.data(), c, 144);
-            if (f == 0 && key == ctx->batch_key && order.size() == n_tiles) {
-                std::memcpy(fo, order.data(), n_tiles * sizeof(uint32_t));
-                std::memcpy(fp, pos.data(), n_tiles * sizeof(uint32_t));
-                actives[f] = ctx->batch_n_active;
-            } else {
-                compute_tile_order_raw(ctx, c, geo_mode, 0, 0, ctx->width, ctx->height, ts, fo, fp, actives[f], G);
-            }
         }
         const uint32_t n_active = actives[f];
         std::memcpy(fd[f].eye, c, 16);
