@@ -380,6 +380,47 @@ def test_render_batch_equals_single_frames(V, O):
             ctx.set_root_skip(0)
         finally:
             ctx.close()
+    # more than eight frames: every XCD takes a run of consecutive frames of a tile position (frame_runs, the default) -- a relabelling of which
+    # block renders which frame, for counts that are and are not multiples of eight, whole frames and a partition's compact tiles
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
+    try:
+        V.VolumeTexture(ctx, O.volume_standin_u8(64))
+        pipe = V.RaycastPipeline(dt_scale=0.5)
+        many = [V.Camera(1.0, 0.5, 1.0 + 0.11 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(24)]
+        singles = []
+        for c in many:
+            ctx.set_camera_blob(c)
+            pipe.record(ctx)
+            singles.append(ctx.read_backbuffer().copy())
+        for B in (9, 19, 24):
+            for runs in (1, 0):
+                ctx.set_param("frame_runs", runs)
+                frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda"))
+                V.render_batch(ctx, pipe, many[:B], frames.data_ptr(), tile_size=ts)
+                ctx.sync()
+                got = frames.cpu().numpy()
+                for k in range(B):
+                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), ("frame runs", runs, B, "whole frames", k)
+                nr = 3
+                cap = V.partition_slots(W, H, ts, nr, 0)
+                gathered = None
+                for r in range(nr):
+                    buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
+                    bid, act = V.render_batch(ctx, pipe, many[:B], buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
+                    if gathered is None:
+                        gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
+                    ctx.sync()
+                    gathered[r] = buf[:act]
+                frames.zero_()
+                torch.cuda.synchronize()
+                V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
+                ctx.sync()
+                got = frames.cpu().numpy()
+                for k in range(B):
+                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), ("frame runs", runs, B, "ranks", nr, k)
+        ctx.set_param("frame_runs", 1)
+    finally:
+        ctx.close()
     # the compute twin (records layout) and the procedural mode (no volume) through the same batched launch
     xcams = [V.Camera(3.0 + 0.1 * k, -0.5 + 0.1 * k, 1.0 + 0.4 * k, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix() for k in range(4)]
     for mode, dt in ((V.MODE_COMPUTE_NEAREST, 1.0), (V.MODE_PROCEDURAL, 3.0)):

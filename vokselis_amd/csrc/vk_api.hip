@@ -34,6 +34,7 @@ struct vk_ctx {
     void *scopy[3] = {nullptr, nullptr, nullptr};  // VK_LAYOUT_STAGED: one brick copy per slow axis
     StagedDesc sdesc{};
     uint32_t stage_cap_bytes = 0, stage_slab_cells = 0, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
+    uint32_t frame_runs = 1;     // batched launches: every XCD marches a run of consecutive frames of a tile position (0: frames x, x + 8, ... as in round 2)
     uint32_t stage_grow_every = 0;  // slab search: try one cell above the last fit every n-th round (0: 4 for u8, 1 for f16; tools/staged_grow.py)
     uint32_t stage_row_pad = 0;  // odd LDS row pitch of the staged window (experiment: tools/staged_row_pad.py)
     uint8_t *dist = nullptr;
@@ -1557,7 +1558,8 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.compact = compact ? 1u : 0u;
     L.dt_scale = dt_scale;
     L.out = out;
-    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr; L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u);
+    L.steps = nullptr; L.counters = nullptr; L.trace = nullptr;
+    L.debug_flags = ((flags & VK_RENDER_PROBE_ALWAYS) ? 0u : 4u) | (ctx->wave_prio ? 16u : 0u) | (ctx->frame_runs ? 32u : 0u);
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
@@ -1915,6 +1917,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     const std::string n(name);
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
+    else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (tools/frame_runs.py)
     else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
     else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;

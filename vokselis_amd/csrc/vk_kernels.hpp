@@ -189,7 +189,16 @@ __device__ __forceinline__ FrameView frame_view(const LaunchDesc &L, uint32_t lb
         const uint32_t sps = L.ts >> 3, per_tile = sps * sps;
         const uint32_t g = lb / per_tile, sub = lb - g * per_tile;  // g: (slot, frame) pairs, frame fastest
         const uint32_t slot = g / L.n_frames;
-        f.frame = g - slot * L.n_frames;
+        uint32_t fr = g - slot * L.n_frames;
+        if (L.debug_flags & 32u) {
+            // Consecutive g go to consecutive XCDs (logical_block), so with the frame index running fastest XCD x would march frames x, x + 8,
+            // x + 16 ... of a tile position.  Under a moving camera neighbouring frames share almost all of their cells (a few pixels of shift),
+            // frames eight apart far fewer: give every XCD a run of CONSECUTIVE frames instead -- residue x of the position takes frames
+            // [start_x, start_x + count_x) -- so that a position's frames meet in one L2, one after the other.  A relabelling only.
+            const uint32_t x = fr & 7u, j = fr >> 3, q = L.n_frames >> 3, rem = L.n_frames & 7u;
+            fr = x * q + min(x, rem) + j;
+        }
+        f.frame = fr;
         f.lb = slot * per_tile + sub;
         const FrameDesc &d = L.frames[f.frame];
 #pragma unroll
