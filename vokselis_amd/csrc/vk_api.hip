@@ -65,6 +65,7 @@ struct vk_ctx {
     unsigned long long *trace = nullptr;
     size_t trace_blocks = 0;
     bool want_trace = false;
+    uint32_t trip_log_cap = 0;   // > 0: the trace buffer holds per-trip logs of that many u32 entries per wave instead of stamps (tools/repack_census.py)
     // The device copies of (order, order_pos) live in a ring of kOrderRing slots fed from pinned staging: a new
     // camera takes the next slot with one stream-ordered copy -- no host or device synchronisation -- while
     // launches still in flight (other streams: frames in flight) keep reading the slots they were given.
@@ -1257,15 +1258,18 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     if (count && ctx->want_trace) {
-        if (ctx->trace_blocks < n_blocks) {
+        // (a per-trip log of trip_log_cap u32 per wave = trip_log_cap / 8 records of the stamps' size)
+        const uint64_t recs = ctx->trip_log_cap ? n_blocks * (ctx->trip_log_cap / 8u) : n_blocks;
+        if (ctx->trace_blocks < recs) {
             if (ctx->trace) (void)hipFree(ctx->trace);
             ctx->trace = nullptr; ctx->trace_blocks = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->trace, n_blocks * 4 * sizeof(unsigned long long)));
-            ctx->trace_blocks = n_blocks;
+            HIP_TRY(ctx, hipMalloc(&ctx->trace, recs * 4 * sizeof(unsigned long long)));
+            ctx->trace_blocks = recs;
         }
         // start = +inf (atomicMin), end = 0 (atomicMax): fill {0xff.., 0} pairs
-        std::vector<unsigned long long> init(n_blocks * 4, 0ull);
-        for (uint64_t i = 0; i < n_blocks; i++) init[4 * i] = ~0ull;
+        std::vector<unsigned long long> init(recs * 4, 0ull);
+        if (ctx->trip_log_cap) L.debug_flags |= 64u | (ctx->trip_log_cap << 16);
+        else for (uint64_t i = 0; i < n_blocks; i++) init[4 * i] = ~0ull;
         HIP_TRY(ctx, hipMemcpy(ctx->trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         L.trace = ctx->trace;
     }
@@ -1917,6 +1921,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     const std::string n(name);
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
+    else if (n == "trip_log_cap") { if (value < 0 || value > 4096 || ((uint32_t)value & 7u)) return fail(ctx, VK_ERR_INVALID, "trip_log_cap: a multiple of 8 up to 4096"); ctx->trip_log_cap = (uint32_t)value; }
     else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (tools/frame_runs.py)
     else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
     else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)

@@ -472,6 +472,10 @@ static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
 struct Census {  // SIMT execution census + step counters (COUNT builds only)
     uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0, n_fb = 0;
     uint32_t skips = 0;  // trips that skipped (every build: drives the adaptive probing policy)
+    // per-trip log of the wave (COUNT builds, debug bit 6; tools/repack_census.py): entry = live lanes | samplers << 7 | samplers whose alpha is
+    // not 0 << 14 | wave-level walk iterations << 21
+    uint32_t *log = nullptr;
+    uint32_t log_cap = 0, trip_no = 0;
 };
 
 // Runs at most `budget` trips of the reference loop (raycast_naive.wgsl:101-119) on the state and
@@ -532,6 +536,11 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     while (t < t1 && A < 0.95f && (!BOUNDED || trip < budget)) {
         if (BOUNDED) ++trip;
         if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
+        uint32_t *le = nullptr;
+        if (COUNT && cs.log) {
+            if (cs.trip_no < cs.log_cap) { le = cs.log + cs.trip_no; atomicAdd(le, 1u); }
+            cs.trip_no++;
+        }
         const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
         int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
         const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
@@ -583,11 +592,11 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 const float tstop4 = fmaf(-3.5f, dt, tstop);  // t < tstop4  =>  t + 3 dt < tstop as well
                 px = px + sx; py = py + sy; pz = pz + sz;
                 t = t + dt;
-                if (COUNT) { n_iter++; if (wave_leader()) w_inner++; }
+                if (COUNT) { n_iter++; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                 while (t < tstop4) {  // four skipped iterations per trip of the walk
 #pragma unroll
                     for (int j = 0; j < 4; j++) { px = px + sx; py = py + sy; pz = pz + sz; t = t + dt; }
-                    if (COUNT) { n_iter += 4; if (wave_leader()) w_inner++; }
+                    if (COUNT) { n_iter += 4; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                 }
                 if (t < tstop2) {
                     // (the empty asm keeps this an exec-masked region: if-converted, the two steps are computed for every lane and
@@ -662,6 +671,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         float c0 = fmaf(fy, c10 - c00, c00), c1 = fmaf(fy, c11 - c01, c01);
         float r = fmaf(fz, c1 - c0, c0);
         const float a = transfer_alpha<(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_LINEAR_U8 || VOL == VOL_B9U8) ? 1 : 0>(r);
+        if (COUNT && le) atomicAdd(le, (1u << 7) + (a != 0.0f ? 1u << 14 : 0u));
         if (SKIP) {
             // A cell is non-empty as soon as one of its 8 taps is above the threshold; the FILTERED value of a sample inside it
             // often is not (a lone voxel just above it, a silhouette), and then alpha is exactly 0: w = 0, every accumulator
@@ -976,6 +986,11 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
     float t0, t1;
     intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
     Census cs;
+    const bool trip_log = COUNT && L.trace && (L.debug_flags & 64u);
+    if (trip_log) {
+        cs.log_cap = L.debug_flags >> 16;
+        cs.log = reinterpret_cast<uint32_t *>(L.trace) + (size_t)lb * cs.log_cap;
+    }
     // colour is accumulated as G = sum w*cos(phase); C = 0.5*A + 0.5*G at the end (sum w == A)
     float Gr = 0.0f, Gg = 0.0f, Gb = 0.0f, A = 0.0f;
     float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
@@ -1038,7 +1053,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
             atomicAdd(&L.counters[4], (unsigned long long)cs.w_sample);
             atomicAdd(&L.counters[5], (unsigned long long)cs.n_look);
         }
-        if (L.trace) {  // stamps leave only through this debug buffer
+        if (L.trace && !trip_log) {  // stamps leave only through this debug buffer
             unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
             atomicMin(&L.trace[4 * (size_t)lb], t_start);
             atomicMax(&L.trace[4 * (size_t)lb + 1], t_end);
