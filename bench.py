@@ -568,6 +568,9 @@ def main():
                                    "note": "aggregate over %d GPU(s): algorithmic bytes of the window's frames / wall time; per-kernel figure: see the N = 1 line" % world}
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
                 out["config"]["root_skip"] = btr.root_skip
+                # what a peer puts on its link to the root per frame: its active slots, colour only (alpha is 1 in every pixel)
+                out["config"]["wire"] = {"format": "rgb" if btr.ch == 3 else "rgba", "bytes_per_pixel": ctx.wire_pixel_bytes,
+                                         "slot_capacity": btr.cap, "tile_bytes": TILE * TILE * ctx.wire_pixel_bytes}
 
         # One frame per launch -- the reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) -- on the
         # config's camera: duration of a single-frame launch and its spread, back to back on a busy GPU.

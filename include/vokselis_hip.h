@@ -163,6 +163,17 @@ int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint
 int vk_partition_root_skip(vk_ctx *ctx, uint32_t root_skip);
 int vk_partition_slots_weighted(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t root_skip,
                                 uint32_t *n_slots);
+/* What a pixel of a partition's compact tiles holds.  VK_WIRE_RGBA (default): the backbuffer's pixel.  VK_WIRE_RGB: its
+ * three colour channels -- every pixel this path writes has alpha 1 (raycast_naive.wgsl:124, raycast_compute.wgsl:143),
+ * and the tiles exist to be moved over xGMI: 6 bytes instead of 8 per rgba16f pixel, a quarter less on the one link
+ * each peer has to the root (which is what bounds an 8-GPU node on the 1080p configuration: DESIGN.md 6).  A (slot,
+ * frame) record is then ts*ts (r, g) pairs followed by ts*ts b values; the un-tile writes alpha = 1.  Set the same
+ * value on every rank before partitioning; it applies to the compact output of vk_render_partition / vk_render_batch,
+ * to vk_gather_tiles (n_pixels counts pixels of this size) and to vk_untile / vk_untile_batch.  Frames are bitwise
+ * what VK_WIRE_RGBA delivers.  vk_wire_pixel_bytes: bytes per pixel of the context's compact tiles. */
+enum { VK_WIRE_RGBA = 0, VK_WIRE_RGB = 1 };
+int vk_partition_wire(vk_ctx *ctx, int wire);
+int vk_wire_pixel_bytes(vk_ctx *ctx, uint32_t *bytes);
 /* The tiles a partition marches and moves ("active"): those the box's projected silhouette -- the convex hull of its 8
  * corners under this camera, 2 px of margin -- can reach; every other tile holds only the clear colour
  * (examples/bonsai/main.rs:41) and is cleared by the root.  Pure host arithmetic, no context: active[] receives
@@ -223,7 +234,7 @@ int vk_comm_unique_id(void *id128);
 int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks);
 int vk_comm_destroy(vk_ctx *ctx);
 int vk_comm_info(vk_ctx *ctx, int *rank, int *nranks);
-/* Every rank contributes n_pixels pixels (backbuffer format) from `send`; the root receives [nranks][n_pixels] in
+/* Every rank contributes n_pixels pixels (of the partition's wire format: vk_partition_wire) from `send`; the root receives [nranks][n_pixels] in
  * `recv` (ignored elsewhere).  One grouped send/recv, asynchronous, on `hip_stream` (NULL: the context's stream; a
  * separate stream lets the gather of one batch overlap the march of the next -- the caller orders the two). */
 int vk_gather_tiles(vk_ctx *ctx, const void *send, void *recv, size_t n_pixels, int root, void *hip_stream);

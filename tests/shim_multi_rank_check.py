@@ -72,6 +72,8 @@ def main():
                     check(c, L.vk_volume_upload(c, vol.ctypes.data, None, nvox, nvox, nvox, V.FMT_R8_UNORM, V.LAYOUT_AUTO))
                 root = C.c_void_p(L.vk_group_ctx(g, 0))
                 check(root, L.vk_partition_root_skip(root, root_skip))
+                wire = V.WIRE_RGB if (n + root_skip) % 2 else V.WIRE_RGBA  # colour-only tiles on the wire in half of the cases
+                check(root, L.vk_partition_wire(root, wire))
                 # a member's communicator is the group's: the per-rank entry points must refuse it
                 assert L.vk_comm_destroy(root) != 0
                 out = C.c_void_p()
@@ -89,10 +91,11 @@ def main():
             t1, b1 = stats()
             assert t1 - t0 == 2 * (n - 1), ("one send/recv pair per peer and call", n, t1 - t0)
             assert fake.fake_rccl_unmatched() == 0
-            print("vk_group_render n=%d root_skip=%d: %d frames bitwise, %d transfers, %.2f MB moved" % (n, root_skip, B, t1 - t0, (b1 - b0) / 1e6))
+            print("vk_group_render n=%d root_skip=%d wire=%s: %d frames bitwise, %d transfers, %.2f MB moved" % (n, root_skip, "rgb" if wire else "rgba", B, t1 - t0, (b1 - b0) / 1e6))
 
     # ---- (a) one context per rank: vk_comm_init_rank + vk_gather_tiles (root branch) --------------------------
-    for n, root_skip, peers_first in ((2, 0, False), (3, 2, True), (8, 3, False)):
+    for n, root_skip, peers_first, wire in ((2, 0, False, V.WIRE_RGBA), (3, 2, True, V.WIRE_RGB), (8, 3, False, V.WIRE_RGB)):
+        ch = 3 if wire == V.WIRE_RGB else 4
         t0, b0 = stats()
         idbuf = (C.c_ubyte * 128)()
         check(None, L.vk_comm_unique_id(idbuf))
@@ -103,6 +106,8 @@ def main():
             V.VolumeTexture(c, vol)
             check(c.handle, L.vk_comm_init_rank(c.handle, bytes(idbuf), r, n))
             c.set_root_skip(root_skip)
+            c.set_wire(wire)
+            assert c.wire_pixel_bytes == 4 * ch
             ctxs.append(c)
             comm_streams.append(torch.cuda.Stream())
         rk, nr = C.c_int(), C.c_int()
@@ -110,8 +115,8 @@ def main():
         assert (rk.value, nr.value) == (n - 1, n)
         cap = V.partition_slots(W, H, ts, n, root_skip)
         pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=dt)
-        send = [torch.zeros((cap, B, ts, ts, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
-        recv = torch.zeros((n * cap * B, ts, ts, 4), dtype=torch.float32, device="cuda")
+        send = [torch.zeros((cap, B, ts * ts * ch), dtype=torch.float32, device="cuda") for _ in range(n)]
+        recv = torch.zeros((n * cap * B, ts * ts * ch), dtype=torch.float32, device="cuda")
         frames = torch.zeros((B, H, W, 4), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         bids, acts = [], []
@@ -146,8 +151,9 @@ def main():
             c.close()
         t1, b1 = stats()
         assert t1 - t0 == n - 1
-        print("vk_gather_tiles n=%d root_skip=%d (%s): %d frames bitwise, %d transfers, %.2f MB moved"
-              % (n, root_skip, "peers post first" if peers_first else "root posts first", B, t1 - t0, (b1 - b0) / 1e6))
+        assert b1 - b0 == (n - 1) * n_px * 4 * ch, "every peer moves its active prefix, in the wire format"
+        print("vk_gather_tiles n=%d root_skip=%d wire=%s (%s): %d frames bitwise, %d transfers, %.2f MB moved"
+              % (n, root_skip, "rgb" if wire else "rgba", "peers post first" if peers_first else "root posts first", B, t1 - t0, (b1 - b0) / 1e6))
     print("shim_multi_rank_check: OK")
 
 

@@ -282,6 +282,15 @@ def test_partition_untile_equals_frame(V, O):
             V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world, slots))
             img = ctx.read_backbuffer()
             assert (img == host).all()
+            # the same partition with colour-only tiles (VK_WIRE_RGB): three quarters of the bytes, the same frame
+            ctx.set_wire(V.WIRE_RGB)
+            lean = _synced(torch.full((world, slots, ts * ts * 3), np.nan, dtype=torch.float32, device="cuda"))
+            for r in range(world):
+                pipe.record_partition(ctx, ts, r, world, lean[r].data_ptr())
+            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, lean.data_ptr(), ts, world, slots))
+            img = ctx.read_backbuffer()
+            assert (img.view(np.uint32) == host.view(np.uint32)).all()
+            ctx.set_wire(V.WIRE_RGBA)
         finally:
             ctx.close()
 
@@ -395,6 +404,11 @@ def test_render_batch_equals_single_frames(V, O):
         for B in (9, 19, 24):
             for runs in (1, 0):
                 ctx.set_param("frame_runs", runs)
+                # (the partition's tiles also as colour only -- VK_WIRE_RGB: (r, g) plane + b plane per record, alpha restored by the un-tile)
+                wire = V.WIRE_RGB if runs else V.WIRE_RGBA
+                ch = 3 if wire == V.WIRE_RGB else 4
+                ctx.set_wire(wire)
+                assert ctx.wire_pixel_bytes == 2 * ch
                 frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda"))
                 V.render_batch(ctx, pipe, many[:B], frames.data_ptr(), tile_size=ts)
                 ctx.sync()
@@ -405,10 +419,10 @@ def test_render_batch_equals_single_frames(V, O):
                 cap = V.partition_slots(W, H, ts, nr, 0)
                 gathered = None
                 for r in range(nr):
-                    buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
+                    buf = _synced(torch.full((cap, B, ts * ts * ch), 7.0, dtype=torch.float16, device="cuda"))
                     bid, act = V.render_batch(ctx, pipe, many[:B], buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
                     if gathered is None:
-                        gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
+                        gathered = _synced(torch.zeros((nr, act, B, ts * ts * ch), dtype=torch.float16, device="cuda"))
                     ctx.sync()
                     gathered[r] = buf[:act]
                 frames.zero_()
@@ -419,6 +433,11 @@ def test_render_batch_equals_single_frames(V, O):
                 for k in range(B):
                     assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), ("frame runs", runs, B, "ranks", nr, k)
         ctx.set_param("frame_runs", 1)
+        # a batch dealt in one wire format (the last one above: whole pixels) is not un-tiled in another
+        ctx.set_wire(V.WIRE_RGB)
+        with pytest.raises(V.VokselisError):
+            V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
+        ctx.set_wire(V.WIRE_RGBA)
     finally:
         ctx.close()
     # the compute twin (records layout) and the procedural mode (no volume) through the same batched launch

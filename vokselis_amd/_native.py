@@ -18,6 +18,7 @@ LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, 
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS = 32, 64
+WIRE_RGBA, WIRE_RGB = 0, 1
 GEN_FOG, GEN_BONSAI_STANDIN, GEN_FOG_DENSE_CORE = 0, 1, 2
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
@@ -44,6 +45,8 @@ SYMBOLS = {
     "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
     "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
     "vk_partition_slots_weighted": (C.c_int, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "vk_partition_wire": (C.c_int, [_vp, C.c_int]),
+    "vk_wire_pixel_bytes": (C.c_int, [_vp, C.POINTER(_u32)]),
     "vk_tiles_active": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, C.POINTER(C.c_ubyte), C.POINTER(_u32)]),
     "vk_partition_root_skip": (C.c_int, [_vp, _u32]),
     "vk_render_partition": (C.c_int, [_vp, C.c_int, _u32, _u32, _u32, _f32, _u32, _vp]),

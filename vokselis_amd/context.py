@@ -194,6 +194,17 @@ class Context:
         """vk_partition_root_skip: rank 0 sits out every k-th round of the tile deal (0: never)."""
         N.check(self._h, N.lib().vk_partition_root_skip(self._h, int(k)))
 
+    def set_wire(self, wire: int):
+        """vk_partition_wire: what a pixel of this context's compact tiles holds (WIRE_RGBA: the backbuffer's pixel; WIRE_RGB:
+        its three colour channels -- alpha is 1 in every pixel the path writes -- a quarter less to move between GPUs)."""
+        N.check(self._h, N.lib().vk_partition_wire(self._h, int(wire)))
+
+    @property
+    def wire_pixel_bytes(self) -> int:
+        n = C.c_uint32(0)
+        N.check(self._h, N.lib().vk_wire_pixel_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
     def set_param(self, name: str, value: float):
         """Debug / tuning knob of the library (vk_debug_set_param)."""
         N.check(self._h, N.lib().vk_debug_set_param(self._h, name.encode(), float(value)))

@@ -64,6 +64,7 @@ struct vk_ctx {
     std::vector<unsigned char> order_key;
     unsigned long long *trace = nullptr;
     size_t trace_blocks = 0;
+    int wire = VK_WIRE_RGBA;     // compact tiles of a partition: whole pixels, or colour only (vk_partition_wire)
     bool want_trace = false;
     uint32_t trip_log_cap = 0;   // > 0: the trace buffer holds per-trip logs of that many u32 entries per wave instead of stamps (tools/repack_census.py)
     // The device copies of (order, order_pos) live in a ring of kOrderRing slots fed from pinned staging: a new
@@ -88,6 +89,7 @@ struct vk_ctx {
         uint32_t id = 0, n_frames = 0, n_tiles = 0, ts = 0, nranks = 0, max_active = 0, root_skip = 0;
         uint32_t width = 0, height = 0;  // the frame shape and pixel format the batch was dealt for: an un-tile under another
         int out_format = -1;             // shape (vk_backbuffer_resize in between) would scatter tiles out of bounds
+        int wire = 0;                    // ... and the wire format its compact tiles were written in
     } batch[4];
     uint32_t batch_seq = 0;
     // table blocks a growing batch has outgrown: hipFree / hipHostFree synchronise the device, so they wait here for a
@@ -138,6 +140,8 @@ static int fail(vk_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 static size_t px_bytes(int fmt) { return fmt == VK_OUT_RGBA16F ? 8 : 16; }
+// a pixel of a partition's compact tiles: the backbuffer's pixel, or its three colour channels (VK_WIRE_RGB)
+static size_t wire_px_bytes(int fmt, int wire) { return wire == VK_WIRE_RGB ? px_bytes(fmt) / 4 * 3 : px_bytes(fmt); }
 
 // ---- RCCL, loaded on first use ---------------------------------------------------------------------
 // librccl is 570 MB; a single-GPU user never pays for it.  dlopen by SONAME finds the copy a host process
@@ -1246,7 +1250,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     const uint64_t n_blocks = slots * per_tile;
     if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large");
     L.n_blocks = (uint32_t)n_blocks;
-    L.compact = compact_out ? 1u : 0u;
+    L.compact = compact_out ? 1u + (uint32_t)ctx->wire : 0u;
     L.dt_scale = dt_scale;
     L.out = compact_out ? compact_out : ctx->backbuffer;
     L.steps = count ? ctx->steps : nullptr;
@@ -1281,6 +1285,19 @@ extern "C" {
 int vk_render(vk_ctx *ctx, int mode, int32_t tile_x, int32_t tile_y, uint32_t tile_w, uint32_t tile_h, float dt_scale,
               uint32_t flags) {
     return render_common(ctx, mode, tile_x, tile_y, tile_w, tile_h, 64, 0, 1, dt_scale, flags, nullptr);
+}
+
+int vk_partition_wire(vk_ctx *ctx, int wire) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (wire != VK_WIRE_RGBA && wire != VK_WIRE_RGB) return fail(ctx, VK_ERR_INVALID, "vk_partition_wire: VK_WIRE_RGBA or VK_WIRE_RGB");
+    ctx->wire = wire;
+    return VK_OK;
+}
+
+int vk_wire_pixel_bytes(vk_ctx *ctx, uint32_t *bytes) {
+    if (!ctx || !bytes) return fail(ctx, VK_ERR_INVALID, "vk_wire_pixel_bytes: NULL argument");
+    *bytes = (uint32_t)wire_px_bytes(ctx->out_format, ctx->wire);
+    return VK_OK;
 }
 
 int vk_partition_slots(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint32_t *n_slots) {
@@ -1401,9 +1418,9 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
     if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile: too many tiles for one launch");
     const uint32_t rs = nranks > 1 ? ctx->root_skip : 0u;
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active, (const uint32_t *)nullptr, (const FrameDesc *)nullptr, (uint32_t)ctx->wire);
     else
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, ctx->backbuffer, ctx->width, ctx->height, tile_size, tiles_x, (uint32_t)n_tiles, nranks, n_slots, 1u, d_pos, (const FrameDesc *)nullptr, rs, n_active, (const uint32_t *)nullptr, (const FrameDesc *)nullptr, (uint32_t)ctx->wire);
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
 }
@@ -1542,7 +1559,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     HIP_TRY(ctx, hipMemcpyAsync(B.d, B.h, bytes, hipMemcpyHostToDevice, ctx->stream));
     B.id = ++ctx->batch_seq;
     B.n_frames = n_frames; B.n_tiles = (uint32_t)n_tiles; B.ts = ts; B.nranks = nranks; B.max_active = max_active; B.root_skip = root_skip;
-    B.width = ctx->width; B.height = ctx->height; B.out_format = ctx->out_format;
+    B.width = ctx->width; B.height = ctx->height; B.out_format = ctx->out_format; B.wire = ctx->wire;
     if (batch_id) *batch_id = B.id;
     // whole frames: the tiles behind a frame's active positions get their clear colour from strips at the end of the grid
     const uint32_t clear_max_inactive = (!compact && geo_mode == VK_MODE_NAIVE_TRILINEAR && min_active < n_tiles) ? (uint32_t)n_tiles - min_active : 0u;
@@ -1559,7 +1576,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     const uint64_t n_blocks = slots * n_frames * per_tile;
     if (n_blocks >= (1ull << 31) - 512) return fail(ctx, VK_ERR_UNSUPPORTED, "launch too large: fewer frames per batch");
     L.n_blocks = (uint32_t)n_blocks;
-    L.compact = compact ? 1u : 0u;
+    L.compact = compact ? 1u + (uint32_t)ctx->wire : 0u;
     L.dt_scale = dt_scale;
     L.out = out;
     L.steps = nullptr; L.counters = nullptr; L.trace = nullptr;
@@ -1588,6 +1605,7 @@ int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, u
         for (auto &b : ctx->batch) if (b.id == prev_batch_id) P = &b;
     if (B->width != ctx->width || B->height != ctx->height || B->out_format != ctx->out_format)
         return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: the backbuffer changed shape or format since that batch was dealt");
+    if (B->wire != ctx->wire) return fail(ctx, VK_ERR_INVALID, "vk_untile_batch: the wire format changed since that batch was dealt (vk_partition_wire)");
     if (P && (P->n_frames != B->n_frames || P->n_tiles != B->n_tiles || P->ts != B->ts || P->width != B->width || P->height != B->height ||
               P->out_format != B->out_format || !P->d)) P = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1601,9 +1619,9 @@ int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, u
     const FrameDesc *pframes = P ? reinterpret_cast<const FrameDesc *>(P->d) : nullptr;
     const uint32_t *ppos = P ? reinterpret_cast<const uint32_t *>(P->d + (size_t)P->n_frames * sizeof(FrameDesc)) + (size_t)P->n_frames * P->n_tiles : nullptr;
     if (ctx->out_format == VK_OUT_RGBA16F)
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes, (uint32_t)B->wire);
     else
-        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes);
+        hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA32F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes, (uint32_t)B->wire);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(B->ev, ctx->stream));
     if (P) HIP_TRY(ctx, hipEventRecord(P->ev, ctx->stream));  // (its tables were read too: the slot is reused after this launch)
@@ -1687,7 +1705,7 @@ int vk_gather_tiles(vk_ctx *ctx, const void *send, void *recv, size_t n_pixels, 
     if (root < 0 || root >= ctx->comm_size) return fail(ctx, VK_ERR_INVALID, "vk_gather_tiles: root out of range");
     if (ctx->comm_rank == root && !recv) return fail(ctx, VK_ERR_INVALID, "vk_gather_tiles: the root needs a receive buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = n_pixels * px_bytes(ctx->out_format);
+    const size_t bytes = n_pixels * wire_px_bytes(ctx->out_format, ctx->wire);
     if (bytes == 0) return VK_OK;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     if (ctx->comm_rank == root) {
@@ -1780,8 +1798,8 @@ int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *camera
     }
     uint32_t cap = 0;
     if (vk_partition_slots_weighted(root->width, root->height, tile_size, (uint32_t)n, root->root_skip, &cap) != VK_OK) { g->err = "vk_group_render: bad tile size"; return VK_ERR_INVALID; }
-    for (int i = 1; i < n; i++) g->ctx[i]->root_skip = root->root_skip;  // one deal for the whole group
-    const size_t tile_bytes = (size_t)tile_size * tile_size * px_bytes(root->out_format);
+    for (int i = 1; i < n; i++) { g->ctx[i]->root_skip = root->root_skip; g->ctx[i]->wire = root->wire; }  // one deal, one wire format for the whole group
+    const size_t tile_bytes = (size_t)tile_size * tile_size * wire_px_bytes(root->out_format, root->wire);
     const size_t need = (size_t)cap * n_frames * tile_bytes;
     if (g->send_bytes < need) {
         for (int i = 0; i < n; i++) {

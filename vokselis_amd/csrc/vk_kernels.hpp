@@ -87,7 +87,7 @@ struct LaunchDesc {
     uint32_t rank, nranks;
     uint32_t root_skip;  // dealing: rank 0 sits out every root_skip-th round (< 2: never)
     uint32_t n_blocks;   // logical 8x8 blocks of this launch
-    uint32_t compact;    // 1: output is [slot][ts][ts], 0: [H][W]
+    uint32_t compact;    // 0: output is [H][W] pixels; 1: [slot][ts][ts] pixels; 2: [slot] records of ts*ts (r, g) pairs followed by ts*ts b values (the lean wire format: alpha is 1 in every pixel this path writes)
     float dt_scale;
     const uint32_t *tile_order;  // position in the heaviest-first order -> tile id (row-major)
     int32_t cull_x0, cull_y0, cull_x1, cull_y1;  // pixels outside [x0,x1) x [y0,y1) cannot hit the box
@@ -168,6 +168,7 @@ struct PixelMap {
     int32_t x, y;      // image coordinates
     bool valid;        // inside region and image
     size_t out_index;  // pixel index into the output
+    uint32_t rec, rec_px;  // compact output: the (slot, frame) record and the pixel inside it (out_index = rec * ts * ts + rec_px)
     uint32_t pos;      // position of the wave's tile in the heaviest-first order (wave-uniform)
 };
 
@@ -243,7 +244,9 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameVi
               m.x < (int32_t)L.W && m.y < (int32_t)L.H;
     const uint32_t nf = L.frames ? L.n_frames : 1u;
     m.pos = pos;
-    m.out_index = L.compact ? (((size_t)slot * nf + fv.frame) * L.ts + ly) * L.ts + lx
+    m.rec = slot * nf + fv.frame;
+    m.rec_px = ly * L.ts + lx;
+    m.out_index = L.compact ? (size_t)m.rec * (L.ts * L.ts) + m.rec_px
                             : ((size_t)fv.frame * L.H + (size_t)m.y) * L.W + (size_t)m.x;
     return m;
 }
@@ -257,6 +260,26 @@ __device__ __forceinline__ void store_pixel(void *out, size_t idx, float r, floa
         union { _Float16 h[4]; uint2 u; } p;
         p.h[0] = (_Float16)r; p.h[1] = (_Float16)g; p.h[2] = (_Float16)b; p.h[3] = (_Float16)a;
         reinterpret_cast<uint2 *>(out)[idx] = p.u;
+    }
+}
+
+// A pixel of a launch: the full (r, g, b, 1) pixel, or -- compact == 2, the lean wire format of a partition -- (r, g) into the
+// record's first plane and b into its second.  Every pixel this path writes has alpha 1 (raycast_naive.wgsl:124,
+// raycast_compute.wgsl:143), and the tiles of a partition exist to be moved over xGMI: 6 bytes instead of 8 (rgba16f).
+template <int OUT>
+__device__ __forceinline__ void store_out(const LaunchDesc &L, const PixelMap &pm, float r, float g, float b) {
+    if (L.compact != 2u) { store_pixel<OUT>(L.out, pm.out_index, r, g, b, 1.0f); return; }  // wave-uniform
+    const size_t tt = (size_t)L.ts * L.ts;
+    if (OUT == OUT_RGBA32F) {
+        float *rec = reinterpret_cast<float *>(L.out) + (size_t)pm.rec * tt * 3u;
+        reinterpret_cast<float2 *>(rec)[pm.rec_px] = make_float2(r, g);
+        rec[tt * 2u + pm.rec_px] = b;
+    } else {
+        _Float16 *rec = reinterpret_cast<_Float16 *>(L.out) + (size_t)pm.rec * tt * 3u;
+        union { _Float16 h[2]; uint32_t u; } q;
+        q.h[0] = (_Float16)r; q.h[1] = (_Float16)g;  // v_cvt_f16_f32, round to nearest even, as store_pixel
+        reinterpret_cast<uint32_t *>(rec)[pm.rec_px] = q.u;
+        rec[tt * 2u + pm.rec_px] = (_Float16)b;
     }
 }
 
@@ -960,7 +983,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         // active positions: a whole-frame launch covers them too, a partition never launches them)
         if (pm.pos >= fv.n_active || bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {
             if (!pm.valid) return;
-            store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
+            store_out<OUT>(L, pm, 0.0f, 0.0f, 0.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
             return;
         }
@@ -1042,7 +1065,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         Cg = linear_to_srgb(fmaf(0.5f, Gg, 0.5f * A));
         Cb = linear_to_srgb(fmaf(0.5f, Gb, 0.5f * A));
     }
-    store_pixel<OUT>(L.out, pm.out_index, Cr, Cg, Cb, 1.0f);
+    store_out<OUT>(L, pm, Cr, Cg, Cb);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 1u) ? cs.n_look : cs.n_iter;
         if (L.counters) {
@@ -1217,7 +1240,7 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
         }
         asm volatile("" ::"v"(nxt.r));  // the last request is consumed on the exit path too (keeps it ahead of the shading)
     }
-    store_pixel<OUT>(L.out, pm.out_index, C[0], C[1], C[2], 1.0f);
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
         if (L.counters) {
@@ -1300,7 +1323,7 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
             if (A >= 0.95f) break;
         }
     }
-    store_pixel<OUT>(L.out, pm.out_index, C[0], C[1], C[2], 1.0f);
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
         if (L.counters) {
@@ -1688,7 +1711,7 @@ __global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDes
             if (!(dt > 0.0f)) break;
         }
     }
-    store_pixel<OUT>(L.out, pm.out_index, C[0], C[1], C[2], 1.0f);
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
         if (L.counters) {
@@ -1772,7 +1795,7 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
                                                            uint32_t tiles_x, uint32_t n_tiles, uint32_t nranks, uint32_t n_slots, uint32_t n_frames,
                                                            const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames, uint32_t root_skip,
                                                            uint32_t n_active_one, const uint32_t *__restrict__ prev_tile_pos = nullptr,
-                                                           const FrameDesc *__restrict__ prev_frames = nullptr) {
+                                                           const FrameDesc *__restrict__ prev_frames = nullptr, uint32_t wire_rgb = 0u) {
     const uint32_t chunks = (ts * ts + 511u) / 512u;  // 512-pixel chunks per tile
     uint32_t b = blockIdx.x;
     const uint32_t chunk = b % chunks; b /= chunks;
@@ -1799,6 +1822,26 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
     uint32_t rank, slot;
     deal_owner(pos, nranks, root_skip, rank, slot);
     const size_t src = ((((size_t)rank * n_slots + slot) * n_frames + frame) * ts + ly) * ts + lx;
+    if (wire_rgb) {  // records of ts*ts (r, g) pairs + ts*ts b values (store_out): alpha is 1
+        const size_t tt = (size_t)ts * ts, rec = ((size_t)rank * n_slots + slot) * n_frames + frame;
+        if (OUT == OUT_RGBA32F) {
+            const float *g = reinterpret_cast<const float *>(gathered) + rec * tt * 3u;
+            const float4 rg = *reinterpret_cast<const float4 *>(g + 2u * l);  // (l even: 16-byte aligned)
+            const float2 bb = *reinterpret_cast<const float2 *>(g + 2u * tt + l);
+            float4 *o = reinterpret_cast<float4 *>(out);
+            o[dst] = make_float4(rg.x, rg.y, bb.x, 1.0f);
+            if (two) o[dst + 1] = make_float4(rg.z, rg.w, bb.y, 1.0f);
+        } else {
+            const uint16_t *g = reinterpret_cast<const uint16_t *>(gathered) + rec * tt * 3u;
+            const uint2 rg = *reinterpret_cast<const uint2 *>(g + 2u * l);
+            const uint32_t bb = *reinterpret_cast<const uint32_t *>(g + 2u * tt + l);
+            uint2 *o = reinterpret_cast<uint2 *>(out);
+            const uint2 p0 = make_uint2(rg.x, (bb & 0xffffu) | 0x3c000000u), p1 = make_uint2(rg.y, (bb >> 16) | 0x3c000000u);  // 0x3c00: 1.0
+            if (two && ((dst & 1u) == 0u)) *reinterpret_cast<uint4 *>(o + dst) = make_uint4(p0.x, p0.y, p1.x, p1.y);
+            else { o[dst] = p0; if (two) o[dst + 1] = p1; }
+        }
+        return;
+    }
     if (OUT == OUT_RGBA32F) {
         const float4 *g = reinterpret_cast<const float4 *>(gathered);
         float4 *o = reinterpret_cast<float4 *>(out);

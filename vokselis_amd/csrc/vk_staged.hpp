@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
         if (pm.pos >= fv.n_active || bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1) {  // wave-uniform
             if (!pm.valid) return;
-            store_pixel<OUT>(L.out, pm.out_index, 0.0f, 0.0f, 0.0f, 1.0f);
+            store_out<OUT>(L, pm, 0.0f, 0.0f, 0.0f);
             if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
             return;
         }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         Cg = linear_to_srgb(fmaf(0.5f, r.Gg, 0.5f * r.A));
         Cb = linear_to_srgb(fmaf(0.5f, r.Gb, 0.5f * r.A));
     }
-    store_pixel<OUT>(L.out, pm.out_index, Cr, Cg, Cb, 1.0f);
+    store_out<OUT>(L, pm, Cr, Cg, Cb);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 2u) ? cs.n_fb : ((L.debug_flags & 1u) ? cs.n_look : cs.n_iter);
         if (L.counters) {

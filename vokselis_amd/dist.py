@@ -119,7 +119,7 @@ class BatchTileRenderer:
     rewrites only the tiles whose state changed).  flush() launches a partial batch and drains."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, batch: int = 16, root: int = 0, group=None,
-                 transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto"):
+                 transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto", wire: int = N.WIRE_RGB):
         import torch
         import torch.distributed as dist
 
@@ -131,6 +131,11 @@ class BatchTileRenderer:
         self.W, self.H = bb.width, bb.height
         self.dtype = torch.float32 if bb.format == N.OUT_RGBA32F else torch.float16
         self.esize = 4 if bb.format == N.OUT_RGBA32F else 2
+        # Tiles travel as colour only (alpha is 1 in every pixel of this path): 6 bytes per rgba16f pixel instead of 8 on the one
+        # xGMI link each peer has to the root.  Every rank constructs this object with the same arguments.
+        ctx.set_wire(wire)
+        self.wire, self.ch = wire, (3 if wire == N.WIRE_RGB else 4)
+        self.tile_elems = tile_size * tile_size * self.ch  # elements of one (slot, frame) record
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self._group = group
         # The march, the un-tile and (torch transport) the gather run on ONE stream of this object's choosing: torch's
@@ -178,7 +183,7 @@ class BatchTileRenderer:
             self.root_skip = self._calibrate_root_skip() if root_skip == "auto" else int(root_skip)
         ctx.set_root_skip(self.root_skip if self.world > 1 else 0)
         self.cap = partition_slots(self.W, self.H, tile_size, self.world, self.root_skip if self.world > 1 else 0)
-        shape = (self.cap, self.batch, tile_size, tile_size, 4)
+        shape = (self.cap, self.batch, self.tile_elems)
         # The buffers are filled (zeroed) on `march_stream`, not on the caller's current stream: torch's streams do not
         # synchronise with the legacy default stream, and a zero-fill still queued there could land AFTER the first march
         # has written its tiles (seen once in ~15 runs of the test that drives this class from the default stream).
@@ -186,7 +191,7 @@ class BatchTileRenderer:
             self.send = [torch.zeros(shape, dtype=self.dtype, device=self.dev) for _ in range(2)]
             self.recv = self.frames = None
             if self.is_root:
-                self.recv = [torch.zeros((self.world * self.cap * self.batch, tile_size, tile_size, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
+                self.recv = [torch.zeros((self.world * self.cap * self.batch, self.tile_elems), dtype=self.dtype, device=self.dev) for _ in range(2)]
                 self.frames = [torch.zeros((self.batch, self.H, self.W, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
         self.marched = [torch.cuda.Event() for _ in range(2)]   # set s: tiles written
         self.moved = [torch.cuda.Event() for _ in range(2)]     # set s: gather done (send[s] free, recv[s] valid)
@@ -237,7 +242,7 @@ class BatchTileRenderer:
         torch = self.torch
         B = min(4, self.batch)
         cap1 = partition_slots(self.W, self.H, self.ts, 1)
-        tiles = torch.zeros((cap1, B, self.ts, self.ts, 4), dtype=self.dtype, device=self.dev)
+        tiles = torch.zeros((cap1, B, self.tile_elems), dtype=self.dtype, device=self.dev)
         frames = torch.zeros((B, self.H, self.W, 4), dtype=self.dtype, device=self.dev)
         cams = [self.ctx.camera_blob] * B
         self.ctx.set_root_skip(0)
@@ -288,7 +293,7 @@ class BatchTileRenderer:
         else:
             self.marched[s].synchronize()
             if act > 0:
-                recv = self.recv[s][: self.world * act * self.batch].view(self.world, act, self.batch, self.ts, self.ts, 4) if self.is_root else None
+                recv = self.recv[s][: self.world * act * self.batch].view(self.world, act, self.batch, self.tile_elems) if self.is_root else None
                 self.tg.gather(self.send[s][:act], recv)
             self.moved[s].record(self.march_stream)
         self._used[s] = True

@@ -53,6 +53,7 @@ static int run_group(int n_gpus, uint32_t frames, uint32_t batch, uint32_t w, ui
             else check(c, vk_volume_generate(c, VK_GEN_BONSAI_STANDIN, 256, 256, 256, VK_FMT_R8_UNORM, 0x5EED0001u, 0, 1, VK_LAYOUT_AUTO));
         }
         vk_ctx *root = vk_group_ctx(g, 0);
+        check(root, vk_partition_wire(root, VK_WIRE_RGB));  // tiles travel as colour only: alpha is 1 in every pixel (6 bytes instead of 8 per link and pixel)
         Camera camera(1.f, 0.5f, 1.f, {0.5f, 0.5f, 0.5f}, (float)w / (float)h);
         std::vector<CameraUniform> cams(batch, camera.get_proj_view_matrix());
         void *out = nullptr;
