@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed pre-roll that brings the GPU to its sustained clocks before the W warm-up frames")
+    ap.add_argument("--no-rotate", action="store_true", help="N > 1: skip the second window with a rotating root (rotating_root in the JSON line)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline's launches (no still-camera window, no single-frame launches): what tools/prof_r3.sh profiles, so that a kernel's mean duration under rocprofv3 is the headline launch's")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather driver even at N = 1 (the like-for-like baseline of the N > 1 lines)")
     return ap.parse_args()
@@ -458,6 +459,7 @@ def main():
             return runs[len(runs) // 2] + (order_ms,)
 
         elapsed, evs, run_order_ms = measure()
+        root_skip_fixed = btr.root_skip if use_dist else 0
         # the same window with the config's ONE camera in every frame (what round 2 reported as the headline)
         still_elapsed, still_evs = None, []
         if not args.headline_only:
@@ -465,6 +467,15 @@ def main():
             timed_region(batch, False)
             still_elapsed, still_evs, _ = measure()
             cams_now[0] = cam_list
+        # N > 1: the same window once more with a ROTATING root (launch g is assembled on rank g mod N): a fixed root takes 7/8 of every
+        # frame over the one link each peer has to it, which at 8 GPUs is slower than the march; rotating spreads the same
+        # bytes over every link of the node.  Reported beside `value`, which stays the gather to rank 0.
+        rot_elapsed = None
+        if use_dist and world > 1 and not args.no_rotate:
+            btr.close()
+            btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root="rotate", transport=transport, via_host=rehearsal)
+            timed_region(batch * min(world, 4), False)
+            rot_elapsed, _, _ = measure()
         n_launch_frames = batch  # frames one launch spans
         launch_ms = None
         if evs:
@@ -566,8 +577,12 @@ def main():
                 out["roofline"] = {"bound": "hbm", "achieved": agg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": agg / (HBM_PEAK_GBS * world), "traffic": None,
                                    "kernel": "whole job (vk::raymarch_naive_kernel per rank + RCCL gather + un-tile, overlapped)",
                                    "note": "aggregate over %d GPU(s): algorithmic bytes of the window's frames / wall time; per-kernel figure: see the N = 1 line" % world}
+                if rot_elapsed is not None:
+                    out["rotating_root"] = {"value": s_ref * timed_frames / rot_elapsed / 1e6, "unit": "Mray-steps/s", "ms_per_step": rot_elapsed / timed_frames * 1e3,
+                                            "note": "the same window with launch g assembled on rank g mod N (BatchTileRenderer(root='rotate')): complete frames end up "
+                                                    "round-robin over the GPUs instead of on rank 0; `value` above is the gather to rank 0"}
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
-                out["config"]["root_skip"] = btr.root_skip
+                out["config"]["root_skip"] = root_skip_fixed
                 # what a peer puts on its link to the root per frame: its active slots, colour only (alpha is 1 in every pixel)
                 out["config"]["wire"] = {"format": "rgb" if btr.ch == 3 else "rgba", "bytes_per_pixel": ctx.wire_pixel_bytes,
                                          "slot_capacity": btr.cap, "tile_bytes": TILE * TILE * ctx.wire_pixel_bytes}

@@ -94,7 +94,9 @@ def main():
             print("vk_group_render n=%d root_skip=%d wire=%s: %d frames bitwise, %d transfers, %.2f MB moved" % (n, root_skip, "rgb" if wire else "rgba", B, t1 - t0, (b1 - b0) / 1e6))
 
     # ---- (a) one context per rank: vk_comm_init_rank + vk_gather_tiles (root branch) --------------------------
-    for n, root_skip, peers_first, wire in ((2, 0, False, V.WIRE_RGBA), (3, 2, True, V.WIRE_RGB), (8, 3, False, V.WIRE_RGB)):
+    # (root: where this gather is assembled -- rank 0, or another rank as BatchTileRenderer(root="rotate") does from launch to launch)
+    for n, root_skip, peers_first, wire, root in ((2, 0, False, V.WIRE_RGBA, 0), (3, 2, True, V.WIRE_RGB, 0), (8, 3, False, V.WIRE_RGB, 0),
+                                                  (3, 0, True, V.WIRE_RGBA, 2), (8, 0, False, V.WIRE_RGB, 5)):
         ch = 3 if wire == V.WIRE_RGB else 4
         t0, b0 = stats()
         idbuf = (C.c_ubyte * 128)()
@@ -127,24 +129,24 @@ def main():
         act = acts[0]
         n_px = act * B * ts * ts
         # the gather on a second stream per rank, ordered behind that rank's march by an event, as the driver does it
-        order = list(range(1, n)) + [0] if peers_first else list(range(n))
+        order = [r for r in range(n) if r != root] + [root] if peers_first else [root] + [r for r in range(n) if r != root]
         for r in order:
             ev = torch.cuda.Event()
             ev.record(march_streams[r])
             comm_streams[r].wait_event(ev)
-            check(ctxs[r].handle, L.vk_gather_tiles(ctxs[r].handle, C.c_void_p(send[r].data_ptr()), C.c_void_p(recv.data_ptr() if r == 0 else None), n_px, 0,
+            check(ctxs[r].handle, L.vk_gather_tiles(ctxs[r].handle, C.c_void_p(send[r].data_ptr()), C.c_void_p(recv.data_ptr() if r == root else None), n_px, root,
                                                     C.c_void_p(comm_streams[r].cuda_stream)))
         assert fake.fake_rccl_unmatched() == 0
         done = torch.cuda.Event()
-        done.record(comm_streams[0])
-        march_streams[0].wait_event(done)
-        V.untile_batch(ctxs[0], bids[0], recv.data_ptr(), act, frames.data_ptr())
-        ctxs[0].sync()
+        done.record(comm_streams[root])
+        march_streams[root].wait_event(done)
+        V.untile_batch(ctxs[root], bids[root], recv.data_ptr(), act, frames.data_ptr())
+        ctxs[root].sync()
         torch.cuda.synchronize()
         got = frames.cpu().numpy()
-        assert (got.view(np.uint32) == want.view(np.uint32)).all(), ("vk_gather_tiles", n, root_skip)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), ("vk_gather_tiles", n, root_skip, root)
         # error behaviour of the gather: a root without a receive buffer, a root out of range
-        assert L.vk_gather_tiles(ctxs[0].handle, C.c_void_p(send[0].data_ptr()), None, n_px, 0, None) != 0
+        assert L.vk_gather_tiles(ctxs[root].handle, C.c_void_p(send[root].data_ptr()), None, n_px, root, None) != 0
         assert L.vk_gather_tiles(ctxs[1].handle, C.c_void_p(send[1].data_ptr()), None, n_px, n, None) != 0
         for c in ctxs:
             check(c.handle, L.vk_comm_destroy(c.handle))
@@ -152,8 +154,8 @@ def main():
         t1, b1 = stats()
         assert t1 - t0 == n - 1
         assert b1 - b0 == (n - 1) * n_px * 4 * ch, "every peer moves its active prefix, in the wire format"
-        print("vk_gather_tiles n=%d root_skip=%d wire=%s (%s): %d frames bitwise, %d transfers, %.2f MB moved"
-              % (n, root_skip, "rgb" if wire else "rgba", "peers post first" if peers_first else "root posts first", B, t1 - t0, (b1 - b0) / 1e6))
+        print("vk_gather_tiles n=%d root_skip=%d root=%d wire=%s (%s): %d frames bitwise, %d transfers, %.2f MB moved"
+              % (n, root_skip, root, "rgb" if wire else "rgba", "peers post first" if peers_first else "root posts first", B, t1 - t0, (b1 - b0) / 1e6))
     print("shim_multi_rank_check: OK")
 
 

@@ -616,11 +616,10 @@ def _btr_two_ranks_worker(rank, world, port, q):
         cams = [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(11)]
         pipe = V.RaycastPipeline(dt_scale=0.5)
         want = []
-        if rank == 0:
-            for c in cams:
-                ctx.set_camera_blob(c)
-                pipe.record(ctx)
-                want.append(ctx.read_backbuffer().view(np.uint16).copy())
+        for c in cams:  # (both ranks: with a rotating root either may be handed a batch)
+            ctx.set_camera_blob(c)
+            pipe.record(ctx)
+            want.append(ctx.read_backbuffer().view(np.uint16).copy())
         bad, seen = [], []
 
         def on_batch(first, count, frames):
@@ -636,8 +635,18 @@ def _btr_two_ranks_worker(rank, world, port, q):
                 r.submit(c)
             r.close()
             ctx.set_stream(None)
+        fixed = (list(seen), list(bad))
+        del seen[:], bad[:]
+        # the same stream of frames with a rotating root: launch g is assembled on rank g mod 2
+        with torch.cuda.stream(torch.cuda.Stream()):
+            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, root="rotate", transport="torch", via_host=True, on_batch=on_batch)
+            assert r.root_skip == 0
+            for c in cams:
+                r.submit(c)
+            r.close()
+            ctx.set_stream(None)
         ctx.close()
-        q.put((rank, seen, bad))
+        q.put((rank, fixed[0], fixed[1], list(seen), list(bad)))
     finally:
         dist.destroy_process_group()
 
@@ -662,7 +671,10 @@ def test_batch_tile_renderer_two_ranks_one_gpu(V, O):
         assert p_.exitcode == 0
     got = sorted(q.get(timeout=10) for _ in range(2))
     assert got[0][0] == 0 and got[0][1] == list(range(11)) and got[0][2] == [], got
-    assert got[1][0] == 1, got
+    assert got[1][0] == 1 and got[1][1] == [], got
+    # rotating root: launches 0 and 2 (frames 0-3, 8-10) land on rank 0, launch 1 (frames 4-7) on rank 1, all bitwise equal
+    assert got[0][3] == [0, 1, 2, 3, 8, 9, 10] and got[0][4] == [], got
+    assert got[1][3] == [4, 5, 6, 7] and got[1][4] == [], got
 
 
 def test_group_api_and_plain_c_consumer(V, O, tmp_path):
@@ -1422,8 +1434,9 @@ def test_bench_multi_rank_flow_rehearsal(V, O, how):
     assert d["timed_frames"] >= 100 and d["timed_frames"] % 24 == 0 and d["launches_per_region"] >= 4
     assert d["frames_per_launch"] * d["launches_per_region"] >= d["timed_frames"]
     assert abs(d["ms_per_step"] * d["timed_frames"] * 1e-3 * d["value"] * 1e6 / (d["config"]["s_ref_per_frame"] * d["timed_frames"]) - 1.0) < 1e-6
-    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "still_camera"):
+    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "still_camera", "rotating_root"):
         assert key in d, key
+    assert d["rotating_root"]["value"] > 0 and d["config"]["wire"]["format"] == "rgb" and d["config"]["wire"]["bytes_per_pixel"] == 6
 
 
 def test_multi_peer_branches_under_fake_rccl(V, O):
@@ -1442,4 +1455,4 @@ def test_multi_peer_branches_under_fake_rccl(V, O):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "shim_multi_rank_check.py")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "shim_multi_rank_check: OK" in r.stdout, r.stdout
-    assert r.stdout.count("vk_group_render n=") == 9 and r.stdout.count("vk_gather_tiles n=") == 3, r.stdout
+    assert r.stdout.count("vk_group_render n=") == 9 and r.stdout.count("vk_gather_tiles n=") == 5, r.stdout

@@ -96,18 +96,20 @@ class TorchTileGather:
         self.dist, self.group, self.root, self.via_host = dist, group, root, via_host
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
-    def gather(self, send, recv):
-        """send: tensor [n, B, ts, ts, 4]; recv (root): tensor [world, n, B, ts, ts, 4].  Blocking."""
+    def gather(self, send, recv, root=None):
+        """send: tensor [n, B, ...]; recv (on the root): tensor [world, n, B, ...].  Blocking.  `root`: this gather's destination
+        (default: the one given at construction)."""
+        root = self.root if root is None else root
         if self.via_host:
             s = send.cpu()
-            out = [s.new_empty(s.shape) for _ in range(self.world)] if self.rank == self.root else None
-            self.dist.gather(s, gather_list=out, dst=self.root, group=self.group)
-            if self.rank == self.root:
+            out = [s.new_empty(s.shape) for _ in range(self.world)] if self.rank == root else None
+            self.dist.gather(s, gather_list=out, dst=root, group=self.group)
+            if self.rank == root:
                 for r in range(self.world):
                     recv[r].copy_(out[r])
             return
-        out = [recv[r] for r in range(self.world)] if self.rank == self.root else None
-        self.dist.gather(send, gather_list=out, dst=self.root, group=self.group)
+        out = [recv[r] for r in range(self.world)] if self.rank == root else None
+        self.dist.gather(send, gather_list=out, dst=root, group=self.group)
 
 
 class BatchTileRenderer:
@@ -116,7 +118,12 @@ class BatchTileRenderer:
     submit(camera_blob) queues a frame; a full batch is launched at once.  On the root, finished batches arrive in
     `on_batch(first_frame_index, count, frames)` with frames a [count, H, W, 4] cuda tensor view (valid until the
     next-but-one batch is launched; READ-ONLY: the next un-tile into that buffer relies on what this one left there and
-    rewrites only the tiles whose state changed).  flush() launches a partial batch and drains."""
+    rewrites only the tiles whose state changed).  flush() launches a partial batch and drains.
+
+    root = "rotate": launch g's frames are assembled on rank g mod world instead of always on one root (on_batch then fires on
+    that rank).  A fixed root receives 7/8 of every frame over the ONE link each peer has to it, and at 8 GPUs on the 1080p
+    configuration those links, not the march, set the pace; rotating the destination spreads the same bytes over all
+    56 directed links of the node -- for consumers that are themselves per GPU (an encoder, a NIC), not for a window on GPU 0."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, batch: int = 16, root: int = 0, group=None,
                  transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto", wire: int = N.WIRE_RGB):
@@ -124,6 +131,8 @@ class BatchTileRenderer:
         import torch.distributed as dist
 
         self.torch = torch
+        self.rotate = root == "rotate"
+        root = 0 if self.rotate else int(root)
         self.ctx, self.pipe, self.ts, self.batch, self.root = ctx, pipeline, tile_size, max(1, int(batch)), root
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.on_batch = on_batch
@@ -180,7 +189,8 @@ class BatchTileRenderer:
         # The root also receives and un-tiles every frame: give it a lighter share of the march (rank 0 sits out every
         # k-th round of the deal).  "auto": k from this GPU's own timings of one batch's march and un-tile.
         with torch.cuda.stream(self.march_stream):
-            self.root_skip = self._calibrate_root_skip() if root_skip == "auto" else int(root_skip)
+            # (a rotating root has no rank that un-tiles more than the others: an even deal)
+            self.root_skip = 0 if self.rotate else (self._calibrate_root_skip() if root_skip == "auto" else int(root_skip))
         ctx.set_root_skip(self.root_skip if self.world > 1 else 0)
         self.cap = partition_slots(self.W, self.H, tile_size, self.world, self.root_skip if self.world > 1 else 0)
         shape = (self.cap, self.batch, self.tile_elems)
@@ -190,7 +200,7 @@ class BatchTileRenderer:
         with torch.cuda.stream(self.march_stream):
             self.send = [torch.zeros(shape, dtype=self.dtype, device=self.dev) for _ in range(2)]
             self.recv = self.frames = None
-            if self.is_root:
+            if self.is_root or self.rotate:
                 self.recv = [torch.zeros((self.world * self.cap * self.batch, self.tile_elems), dtype=self.dtype, device=self.dev) for _ in range(2)]
                 self.frames = [torch.zeros((self.batch, self.H, self.W, 4), dtype=self.dtype, device=self.dev) for _ in range(2)]
         self.marched = [torch.cuda.Event() for _ in range(2)]   # set s: tiles written
@@ -198,8 +208,9 @@ class BatchTileRenderer:
         self._used = [False, False]
         self._frames_bid = [0, 0]  # the batch last un-tiled into frames[s] (0: none yet -- the buffer holds zeros, not the clear colour)
         self._cams, self._set = [], 0
-        self._pending = None  # (set, batch id, active slots, count, first index)
+        self._pending = None  # (set, batch id, active slots, count, first index, root of that launch)
         self._submitted = 0
+        self._launches = 0
 
     @property
     def is_root(self) -> bool:
@@ -284,31 +295,34 @@ class BatchTileRenderer:
         self.marched[s].record(self.march_stream)
         # the gather of this batch, on the communication stream
         n_px = act * self.batch * self.ts * self.ts
+        root = (self._launches % self.world) if self.rotate else self.root
+        self._launches += 1
+        mine = self.rank == root
         if self.transport == "rccl":
             self.comm_stream.wait_event(self.marched[s])
-            recv_ptr = self.recv[s].data_ptr() if self.is_root else None
-            N.check(self.ctx.handle, N.lib().vk_gather_tiles(self.ctx.handle, C.c_void_p(self.send[s].data_ptr()), C.c_void_p(recv_ptr), n_px, self.root,
+            recv_ptr = self.recv[s].data_ptr() if mine else None
+            N.check(self.ctx.handle, N.lib().vk_gather_tiles(self.ctx.handle, C.c_void_p(self.send[s].data_ptr()), C.c_void_p(recv_ptr), n_px, root,
                                                             C.c_void_p(self.comm_stream.cuda_stream)))
             self.moved[s].record(self.comm_stream)
         else:
             self.marched[s].synchronize()
             if act > 0:
-                recv = self.recv[s][: self.world * act * self.batch].view(self.world, act, self.batch, self.tile_elems) if self.is_root else None
-                self.tg.gather(self.send[s][:act], recv)
+                recv = self.recv[s][: self.world * act * self.batch].view(self.world, act, self.batch, self.tile_elems) if mine else None
+                self.tg.gather(self.send[s][:act], recv, root)
             self.moved[s].record(self.march_stream)
         self._used[s] = True
         # the previous batch is on the root by now (its gather overlapped this march): un-tile and deliver it
         self._finish_pending()
-        self._pending = (s, bid, act, count, self._submitted)
+        self._pending = (s, bid, act, count, self._submitted, root)
         self._submitted += count
         self._cams, self._set = [], s ^ 1
 
     def _finish_pending(self):
         if self._pending is None:
             return
-        s, bid, act, count, first = self._pending
+        s, bid, act, count, first, root = self._pending
         self._pending = None
-        if not self.is_root:
+        if self.rank != root:
             return
         self.march_stream.wait_event(self.moved[s])
         # frames[s] still holds what this object un-tiled into it two batches ago: only tiles whose state changed are cleared
