@@ -470,12 +470,16 @@ def main():
         # N > 1: the same window once more with a ROTATING root (launch g is assembled on rank g mod N): a fixed root takes 7/8 of every
         # frame over the one link each peer has to it, which at 8 GPUs is slower than the march; rotating spreads the same
         # bytes over every link of the node.  Reported beside `value`, which stays the gather to rank 0.
-        rot_elapsed = None
+        rot_elapsed, rot_error = None, None
         if use_dist and world > 1 and not args.no_rotate:
-            btr.close()
-            btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root="rotate", transport=transport, via_host=rehearsal)
-            timed_region(batch * min(world, 4), False)
-            rot_elapsed, _, _ = measure()
+            try:  # (a failure here must not cost the line its headline: it is reported in rotating_root instead)
+                btr.close()
+                btr = None
+                btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root="rotate", transport=transport, via_host=rehearsal)
+                timed_region(batch * min(world, 4), False)
+                rot_elapsed, _, _ = measure()
+            except Exception as e:  # noqa: BLE001
+                rot_error = repr(e)
         n_launch_frames = batch  # frames one launch spans
         launch_ms = None
         if evs:
@@ -577,6 +581,8 @@ def main():
                 out["roofline"] = {"bound": "hbm", "achieved": agg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": agg / (HBM_PEAK_GBS * world), "traffic": None,
                                    "kernel": "whole job (vk::raymarch_naive_kernel per rank + RCCL gather + un-tile, overlapped)",
                                    "note": "aggregate over %d GPU(s): algorithmic bytes of the window's frames / wall time; per-kernel figure: see the N = 1 line" % world}
+                if rot_error is not None:
+                    out["rotating_root"] = {"error": rot_error}
                 if rot_elapsed is not None:
                     out["rotating_root"] = {"value": s_ref * timed_frames / rot_elapsed / 1e6, "unit": "Mray-steps/s", "ms_per_step": rot_elapsed / timed_frames * 1e3,
                                             "note": "the same window with launch g assembled on rank g mod N (BatchTileRenderer(root='rotate')): complete frames end up "
@@ -761,7 +767,7 @@ def main():
             cb, s_cpu = cpu_baseline(blob)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["s_ref_matches_gpu"] = (s_cpu == s_ref_still)
-        if use_dist:
+        if use_dist and btr is not None:
             btr.close()
         ctx.close()
         # the other single-GPU BASELINE configs (their own contexts: the C2 volume is gone by now)
