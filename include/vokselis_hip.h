@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2
+#define VK_ABI_VERSION 3
 
 typedef struct vk_ctx vk_ctx;
 
