@@ -775,7 +775,12 @@ def test_staged_bricks_equal_linear_bitwise(V, O, golden_volumes):
             "far": O.camera_blob(3.0, -0.6, 4.0, (0.5, 0.5, 0.5), 1.5)}
     knobs = {"default": (), "tiny_window": (("stage_cap_bytes", 1024),), "thin_slabs": (("stage_slab_cells", 2), ("stage_cap_bytes", 4096)),
              "thick_slabs": (("stage_slab_cells", 27), ("stage_cap_bytes", 32768)), "copy_x_only": (("stage_copies_mask", 1),),
-             "copy_y_only": (("stage_copies_mask", 2),), "copy_z_only": (("stage_copies_mask", 4),)}
+             "copy_y_only": (("stage_copies_mask", 2),), "copy_z_only": (("stage_copies_mask", 4),),
+             # one window per 256-thread group of four waves (raymarch_staged_group_kernel): default budget, a budget that forces thin slabs and
+             # the global-memory fallback, thin and thick slabs
+             "group": (("stage_group", 1),), "group_tiny_window": (("stage_group", 1), ("stage_cap_bytes", 1024)),
+             "group_thin_slabs": (("stage_group", 1), ("stage_slab_cells", 2), ("stage_cap_bytes", 4096)),
+             "group_thick_slabs": (("stage_group", 1), ("stage_slab_cells", 27), ("stage_cap_bytes", 16384)), "group_copy_x_only": (("stage_group", 1), ("stage_copies_mask", 1))}
     W, H = 96, 64
     saw_fallback = saw_short = False
     for vname, vol in vols.items():
@@ -813,6 +818,8 @@ def test_staged_fuzz_dims_cameras_dt(V, O):
                             tuple(float(v) for v in rng.uniform(0.2, 0.8, 3)), W / H)
         dt = float(rng.choice([0.11, 0.37, 0.5, 1.0, 2.3]))
         params = (("stage_cap_bytes", 2048),) if case % 3 == 0 else ()
+        if case % 2 == 0 or case % 7 == 0:
+            params = params + (("stage_group", 1),)  # windows shared by the four waves of a group
         ref, rsteps, _ = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_LINEAR)
         img, steps, _ = _render_with_params(V, cam, vol, W, H, dt, V.LAYOUT_STAGED, params)
         assert (steps == rsteps).all(), (case, dims, dt)

@@ -34,6 +34,7 @@ struct vk_ctx {
     void *scopy[3] = {nullptr, nullptr, nullptr};  // VK_LAYOUT_STAGED: one brick copy per slow axis
     StagedDesc sdesc{};
     uint32_t stage_cap_bytes = 0, stage_slab_cells = 0, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
+    uint32_t stage_group = 2;    // staged march: one LDS window per 256-thread group of four waves (vk_staged.hpp: raymarch_staged_group_kernel): 0 never, 1 always, 2 where it pays (launch_staged)
     uint32_t frame_runs = 1;     // batched launches: every XCD marches a run of consecutive frames of a tile position (0: frames x, x + 8, ... as in round 2)
     uint32_t stage_grow_every = 0;  // slab search: try one cell above the last fit every n-th round (0: 4 for u8, 1 for f16; tools/staged_grow.py)
     uint32_t stage_row_pad = 0;  // odd LDS row pitch of the staged window (experiment: tools/staged_row_pad.py)
@@ -852,6 +853,30 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     // u8 (at the issue-slot limit): every 4th round -- C5 10.40 -> 10.12 ms, other views +-1 %; f16 (waiting on fills, not on slots): every round
     D.grow_every = ctx->stage_grow_every ? ctx->stage_grow_every : (VOL == VOL_S8U8 ? 4u : 1u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+    // One window for the four waves of a 256-thread group (2 x 2 neighbouring 8x8 blocks) instead of one per wave: the rays of 16 x 16 pixels
+    // sweep far less than four 8 x 8 boxes, so the slab is ~twice as thick and a ray meets half as many rounds -- against two barriers
+    // per round.  Measured (tools/staged_group.py, staged_group_sweep.py; frames bitwise equal): it pays where the wave is starved of LDS --
+    // u8 volumes seen from close by (C5: 10.05 -> 9.79 ms; four orbit frames per launch 9.25 -> 9.17; 6.25 KiB per wave and slabs up to 24 cells
+    // read 9.83 single but 9.30 in the 4-frame launch: the per-wave budget stays) -- and costs where the budget is large
+    // already (far views: a workgroup's 64 KiB is less than four waves' 80) or the launch is one partial round of waves (C4: single frame
+    // +2.5 %, four orbit frames per launch 1.67 -> 1.58 ms: f16 takes it in launches of four frames or more).  stage_group: 0 never, 1 always,
+    // 2 (default) by these rules.
+    const bool group = (L.ts & 15u) == 0u && (ctx->stage_group == 1u || (ctx->stage_group == 2u && !ctx->stage_cap_bytes &&
+                                                                                 (VOL == VOL_S8U8 ? cap_auto <= 6400u : (L.frames != nullptr && L.n_frames >= 4u && cap_auto <= 16384u))));
+    if (group) {
+        if (!ctx->stage_slab_cells) D.slab_cells = std::min(2u * D.slab_cells, 32u);  // four waves' LDS hold a slab about twice as thick
+        const uint32_t lds = std::min(D.cap_bytes * kGroupWaves, 65536u) & ~15u;  // four waves' LDS, less the exchange block
+        D.cap_bytes = lds - kGroupExchBytes;
+        const uint32_t groups = (grid + kGroupWaves - 1u) / kGroupWaves;
+        if (f16) {
+            if (count) hipLaunchKernelGGL((raymarch_staged_group_kernel<VOL, OUT_RGBA16F, true>), dim3(groups), dim3(256), lds, ctx->stream, L, V, D);
+            else hipLaunchKernelGGL((raymarch_staged_group_kernel<VOL, OUT_RGBA16F, false>), dim3(groups), dim3(256), lds, ctx->stream, L, V, D);
+        } else {
+            if (count) hipLaunchKernelGGL((raymarch_staged_group_kernel<VOL, OUT_RGBA32F, true>), dim3(groups), dim3(256), lds, ctx->stream, L, V, D);
+            else hipLaunchKernelGGL((raymarch_staged_group_kernel<VOL, OUT_RGBA32F, false>), dim3(groups), dim3(256), lds, ctx->stream, L, V, D);
+        }
+        return;
+    }
     if (f16) {
         if (count) hipLaunchKernelGGL((raymarch_staged_kernel<VOL, OUT_RGBA16F, true>), dim3(grid), dim3(64), D.cap_bytes, ctx->stream, L, V, D);
         else hipLaunchKernelGGL((raymarch_staged_kernel<VOL, OUT_RGBA16F, false>), dim3(grid), dim3(64), D.cap_bytes, ctx->stream, L, V, D);
@@ -1940,6 +1965,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
     else if (n == "trip_log_cap") { if (value < 0 || value > 4096 || ((uint32_t)value & 7u)) return fail(ctx, VK_ERR_INVALID, "trip_log_cap: a multiple of 8 up to 4096"); ctx->trip_log_cap = (uint32_t)value; }
+    else if (n == "stage_group") ctx->stage_group = (uint32_t)value;             // staged march: windows shared by the four waves of a group (tools/staged_group.py)
     else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (tools/frame_runs.py)
     else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
     else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)

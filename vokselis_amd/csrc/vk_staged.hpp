@@ -411,6 +411,207 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     r.t = t; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
+// ---- the same march with ONE window for the four waves of a 256-thread group (2 x 2 neighbouring 8x8 blocks) ------------------
+// A round's fixed work -- slab start, lateral bounds, slab search, fill -- is paid per round; the rays of 16 x 16 pixels sweep a box that is
+// far smaller than four boxes of 8 x 8 pixels (the lateral drift of oblique rays and the 16-byte piece granularity are paid once), so with
+// four waves' LDS the slab is about twice as thick and a ray meets half as many rounds.  Everything that was wave-uniform in
+// march_staged_perm is group-uniform here: the copy, the direction of travel, the slab, the box, `fits` -- exchanged through a few LDS
+// accumulators (one lane per wave: ds_min / ds_max; a barrier; a broadcast read).  Two barriers per round (three when the slab start has
+// to be found by a reduction): bounds -> fill -> steps.  No wave leaves the loop before the whole group is done (a wave without live
+// rays still fills its share), so every wave executes the same barriers.  The arithmetic per ray is march_staged_perm's: frames are
+// bitwise equal.
+constexpr uint32_t kGroupWaves = 4u, kGroupExchBytes = 256u;
+constexpr uint32_t kGroupAccI = 0u, kGroupAccS = 16u, kGroupAccB = 24u;  // int offsets: 9 set-up sums | 2 x {any, sig} | 2 x {any, bMl, bMh, bFl, bFh, -, -, -}
+
+template <int VOL, int PERM, bool COUNT>
+__device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, const StagedDesc &D, RayState &r, bool alive, Census &cs, const uint32_t lane,
+                                                        const uint32_t wave, const bool dir_up) {
+    constexpr int S = PERM, F = (PERM + 1) % 3, M = (PERM + 2) % 3;
+    constexpr bool U8 = (VOL == VOL_S8U8);
+    constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
+    extern __shared__ unsigned char stage_win[];
+    int *const ex = reinterpret_cast<int *>(stage_win);  // the group's exchange block (kGroupExchBytes), then the window
+    const uint32_t win_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage_win + kGroupExchBytes;  // LDS byte address of the window
+    float t = r.t, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    float p[3] = {r.px, r.py, r.pz};
+    const float s[3] = {r.sx, r.sy, r.sz}, t1 = r.t1, dt = r.dt;
+    const float fn[3] = {(float)V.nx, (float)V.ny, (float)V.nz};
+    const unsigned char *const base = D.copy[PERM];
+    const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM], cap = D.cap_bytes;
+    const int T0 = (int)D.slab_cells;
+    const int nvm1[3] = {(int)D.nv[0] - 1, (int)D.nv[1] - 1, (int)D.nv[2] - 1};
+
+    alive = alive && (t < t1 && A < 0.95f);
+    const float duS = s[S] * fn[S];  // cells per step along S
+    // (dir_up: the GROUP's direction of travel along S, decided by the kernel over all four waves)
+    const bool fit = alive && (dir_up ? duS >= 0.2f : duS <= -0.2f);
+    const float inv = fit ? 1.0f / duS : 0.0f;
+    const float ratM = (s[M] * fn[M]) * inv, ratF = (s[F] * fn[F]) * inv;  // lateral cells per cell of S
+
+    int Tprev = T0, sig_next = 0;
+    uint32_t round_no = 0;
+    bool have_sig = false;
+    const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
+    uint32_t par = 0;  // the exchange accumulators alternate between two sets (see group_exchange)
+    for (;;) {
+        const bool live = fit && (t < t1 && A < 0.95f);
+        const int any_mine = __ballot(live) != 0ull ? 1 : 0;
+        const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
+        const int iS = cvt_floor_i32(uS);
+        // The slab starts at the rearmost live ray -- found by a reduction in the first round and after a fallback round;
+        // after a marched slab every live ray has left it (or was ahead of it), so the cell behind its far plane is a valid
+        // start without looking (if the rearmost ray is further on, the slab only holds a few unused cells).
+        int sig = sig_next;
+        if (!have_sig) {  // group-uniform: the rearmost live ray of the four waves
+            const int mine = dir_up ? wave_min_i32(live ? iS : 0x7fffffff) : wave_max_i32(live ? iS : (int)0x80000000);
+            int *const as = ex + kGroupAccS + par * 2;
+            if (lane == 0u) { atomicMax(as, any_mine); if (dir_up) atomicMin(as + 1, mine); else atomicMax(as + 1, mine); }
+            __syncthreads();
+            const int any_g = __builtin_amdgcn_readfirstlane(as[0]);
+            sig = __builtin_amdgcn_readfirstlane(as[1]);
+            if (any_g == 0) break;  // nobody in the group has a live ray that travels with it
+        }
+        // The box changes slowly from round to round: the search starts at the last fit, and one above it only every `grow_every`-th round
+        // (tried every round, the thicker slab fails most of the time -- ~25 scalar instructions of a round's ~240, on a kernel at its
+        // issue-slot limit).  Any T is exact: a thinner slab only means more rounds.
+        int T = min(T0, Tprev + ((round_no++ % D.grow_every) == 0u ? 1 : 0));
+        int clo = dir_up ? sig : sig - T + 1;
+        const bool inslab = live && (uint32_t)(iS - clo) < (uint32_t)T;
+        // lateral bounds of the rays in the slab: from here to the slab's far plane
+        const float e = (dir_up ? (float)(clo + T) : (float)clo) - uS;
+        const float eM = fmaf(e, ratM, uM), eF = fmaf(e, ratF, uF);
+        const int kMl = cvt_floor_i32(fminf(uM, eM) * 64.0f), kMh = cvt_floor_i32(fmaxf(uM, eM) * 64.0f);
+        const int kFl = cvt_floor_i32(fminf(uF, eF) * 64.0f), kFh = cvt_floor_i32(fmaxf(uF, eF) * 64.0f);
+        int bMl, bMh, bFl, bFh;
+        // (the four selects through an SGPR-pair mask: four v_cndmask in a row through VCC, as the compiler writes them, cost ~16 issue
+        // cycles each -- profiles/r03_ubench_valu_issue_rate.txt -- against 4 in this form)
+        const unsigned long long in_mask = __ballot(inslab);
+        wave_minmax4(select_i32(in_mask, kMl, 0x7fffffff), select_i32(in_mask, kMh, (int)0x80000000), select_i32(in_mask, kFl, 0x7fffffff), select_i32(in_mask, kFh, (int)0x80000000), bMl, bMh, bFl, bFh);
+        {   // ... and over the group: LDS atomics by one lane per wave, a barrier, one broadcast read.  The barrier is also the one between the
+            // steps of the round before (window reads) and this round's fill (window writes).
+            int *const ab = ex + kGroupAccB + par * 8;
+            if (lane == 0u) { atomicMax(ab, any_mine); atomicMin(ab + 1, bMl); atomicMax(ab + 2, bMh); atomicMin(ab + 3, bFl); atomicMax(ab + 4, bFh); }
+            __syncthreads();
+            const int any_g = __builtin_amdgcn_readfirstlane(ab[0]);
+            bMl = __builtin_amdgcn_readfirstlane(ab[1]); bMh = __builtin_amdgcn_readfirstlane(ab[2]);
+            bFl = __builtin_amdgcn_readfirstlane(ab[3]); bFh = __builtin_amdgcn_readfirstlane(ab[4]);
+            // the other set is idle until the next round's atomics, which every wave issues after the barrier below: reset it now
+            if (wave == 0u && lane < 8u) {
+                const uint32_t o = par ^ 1u;
+                ex[kGroupAccB + o * 8 + lane] = (lane == 0u || lane > 4u) ? 0 : ((lane & 1u) ? 0x7fffffff : (int)0x80000000);
+                if (lane < 2u) ex[kGroupAccS + o * 2 + lane] = lane == 0u ? 0 : (dir_up ? 0x7fffffff : (int)0x80000000);
+            }
+            if (any_g == 0) break;  // group-uniform
+        }
+        bMl -= 2; bMh += 3; bFl -= 2; bFh += 3;
+        const int ilM = min(max((bMl >> 6) + kStagePad, 0), nvm1[M]), ihM = min(max((bMh >> 6) + kStagePad + 1, 0), nvm1[M]);  // + 1: the upper tap
+        const int ilF = min(max((bFl >> 6) + kStagePad, 0), nvm1[F]), ihF = min(max((bFh >> 6) + kStagePad + 1, 0), nvm1[F]);
+        const uint32_t pf0 = (uint32_t)ilF >> VSH, Efn = ((uint32_t)ihF >> VSH) - pf0 + 1u, Em = (uint32_t)(ihM - ilM) + 1u;
+        // row pitch in pieces: the pieces the rays need, plus one when that makes the pitch odd (row_pad): rows of 4 pieces (64 B) put every
+        // fourth window row -- i.e. every second pixel row of the wave -- on the same LDS banks.  The extra piece is fetched like the others
+        // (the DMA writes 64 consecutive pieces per instruction: a hole cannot be skipped) and never read.
+        const uint32_t Efp = (D.row_pad && !(Efn & 1u) && Efn < 64u) ? Efn + 1u : Efn;
+        // the thickest slab whose box fits the window (scalar)
+        int ilS;
+        uint32_t Es;
+        bool fits;
+        for (;;) {
+            clo = dir_up ? sig : sig - T + 1;
+            ilS = min(max(clo + kStagePad, 0), nvm1[S]);
+            Es = (uint32_t)(min(max(clo + T + kStagePad, 0), nvm1[S]) - ilS) + 1u;  // cells clo .. clo+T-1 and the upper tap
+            fits = Efp <= 64u && Em <= 256u && Es * Em * Efp * 16u <= cap;  // (a group's box is taller than a wave's)
+            if (fits || T == 1) break;
+            T--;
+        }
+        Tprev = T;
+        have_sig = fits;
+        sig_next = dir_up ? clo + T : clo - 1;
+        if (fits) {
+            // ---- fill: piece (slice, q) of the window [slow][mid][fast-piece] <- its 16 bytes in the copy.  A lane keeps its
+            // (row, piece) of the slice, i.e. a 32-bit offset inside one layer of bricks, for every slice; the slice only
+            // moves the wave-uniform base: no vector arithmetic per load.
+            const uint32_t slicePieces = Em * Efp;
+            const uint32_t mgF = kStageMagic[Efp];
+            for (uint32_t j = wave * 64u; j < slicePieces; j += 64u * kGroupWaves) {  // chunks of 64 pieces, dealt over the group's waves
+                const uint32_t q = j + lane;
+                if (q < slicePieces) {
+                    const uint32_t m = Efp == 1u ? q : __umulhi(q, mgF);
+                    const uint32_t f = q - m * Efp;
+                    const uint32_t mm = (uint32_t)ilM + m;
+                    const uint32_t voff = ((pf0 + min(f, Efn - 1u) + npf * (mm >> 3)) << 10) | ((mm & 7u) << 4);  // (f == Efn: the pad piece repeats the row's last one)
+                    // global_load_lds_dwordx4 with the slice's base in a scalar pair and the lane's 32-bit offset: no vector
+                    // arithmetic per load (the builtin only takes a 64-bit per-lane address: one v_lshl_add_u64 each).  The
+                    // base moves by 128 bytes per slice inside a layer of bricks and by the rest of the layer at a brick
+                    // boundary; M0 (the LDS destination) is saved and restored once around the slices.
+                    uint32_t sv = (uint32_t)ilS;
+                    const unsigned char *sbase = base + layerB * (uint64_t)(sv >> 3) + ((sv & 7u) << 7);
+                    uint32_t lds_dst = win_lds + j * 16u;
+                    uint32_t keep_m0;
+                    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+                    for (uint32_t si = 0; si < Es;) {
+                        const uint32_t run = min(8u - (sv & 7u), Es - si);  // slices left in this layer of bricks
+                        for (uint32_t k = 0; k < run; k++) {
+                            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+                            sbase += 128;
+                            lds_dst += slicePieces * 16u;
+                        }
+                        si += run; sv += run;
+                        sbase += layerB - 1024u;  // (from the end of this layer's 8 slices to the next layer's first)
+                    }
+                    asm volatile("s_mov_b32 m0, %0" : : "s"(keep_m0) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // every wave's share of the window has landed
+            // ---- the steps inside the slab, taps from the window
+            const int rowB = (int)(Efp * 16u), sliceB = (int)(Em * Efp * 16u);
+            const int cbase = (kStagePad - ilS) * sliceB + (kStagePad - ilM) * rowB + (kStagePad - (int)(pf0 << VSH)) * BPV + (int)win_lds;
+            if (live) {
+                for (;;) {
+                    const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
+                    const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
+                    // one exit test per step: the ray ended (:101, :115-117) or left the slab (or has not reached it)
+                    if (!((int)(t < t1) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
+                    const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+                    const int a0 = mad_i24(i[S], sliceB, mad_i24(i[M], rowB, i[F] * BPV + cbase));  // |operands| < 2^23
+                    uint32_t lo[4], hi[4];
+                    lds_tap_pairs<U8>((uint32_t)a0, (uint32_t)(a0 + rowB), (uint32_t)(a0 + sliceB), (uint32_t)(a0 + sliceB + rowB), lo, hi);
+                    const float v = filter_pairs<U8, PERM>(lo, hi, fx, fy, fz);
+                    composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
+                    if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
+                    p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
+                    t = t + dt;
+                }
+            }
+        } else {
+            __syncthreads();  // (keeps the rounds' barrier count uniform: the accumulator reset above relies on it)
+          if (live && iS == sig) {
+            // ---- even a one-cell slab exceeds the window: the rearmost rays take one step from global memory
+            const float v = sample_global<VOL, PERM>(D, p, fn);
+            composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
+            if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
+            p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
+            t = t + dt;
+          }
+        }
+        if (COUNT && wave_leader()) { cs.w_outer++; if (!fits) cs.w_inner++; cs.w_sample += (uint32_t)T; }
+        par ^= 1u;
+    }
+    // rays that do not travel with the wave along S
+    if (__ballot(alive && !fit) != 0ull) {
+        if (alive && !fit) {
+            while (t < t1 && A < 0.95f) {
+                const float v = sample_global<VOL, PERM>(D, p, fn);
+                composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
+                if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
+                p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
+                t = t + dt;
+            }
+        }
+    }
+    r.t = t; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+}
+
 // fs_main (raycast_naive.wgsl:83-125) on the staged layout.  Same ray set-up, output and counters as
 // raymarch_naive_kernel; no lane leaves before the march: all 64 take part in the reductions and the fills.
 template <int VOL, int OUT, bool COUNT>
@@ -489,6 +690,125 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             atomicAdd(&L.counters[2], (unsigned long long)cs.w_outer);   // rounds
             atomicAdd(&L.counters[3], (unsigned long long)cs.w_inner);   // rounds served from global memory
             atomicAdd(&L.counters[4], (unsigned long long)cs.w_sample);  // sum of K over rounds
+            atomicAdd(&L.counters[5], (unsigned long long)cs.n_look);
+        }
+    }
+}
+
+// The same pass with one window per 256-thread group: the four waves of a group are the 2 x 2 neighbouring 8x8 blocks of a tile (tile
+// edge a multiple of 16).  Workgroups go round-robin over the XCDs, so a run of 128 consecutive groups gives every XCD the 16 groups of one
+// 64 x 64 tile, as logical_block does for single waves.  No wave returns before the march unless the whole group does.
+template <int VOL, int OUT, bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void raymarch_staged_group_kernel(const LaunchDesc L, const VolumeDesc V, const StagedDesc D) {
+    static_assert(VOL == VOL_S8U8 || VOL == VOL_S8F16, "staged layouts");
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x * kGroupWaves >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x * kGroupWaves + wave - L.grid_march, lane); return; }  // group-uniform
+    uint32_t lb;
+    {
+        const uint32_t G = blockIdx.x, chunk = G >> 7, rr = G & 127u;
+        const uint32_t LG = (chunk << 7) + ((rr & 7u) << 4) + (rr >> 3);
+        const uint32_t sps = L.ts >> 3, per_tile = sps * sps, hq = sps >> 1;  // 8x8 blocks per tile edge (even), quads per tile edge
+        const uint32_t l4 = LG * kGroupWaves + wave, u = l4 % per_tile, q = u >> 2, w = u & 3u;
+        const uint32_t qy = q / hq, qx = q - qy * hq;
+        lb = (l4 - u) + (2u * qy + (w >> 1)) * sps + 2u * qx + (w & 1u);
+    }
+    if (lb >= L.n_blocks) return;  // group-uniform: n_blocks is a multiple of the blocks of a tile
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
+    if (pm.pos >= fv.n_active) {  // group-uniform: the whole tile is inactive
+        if (!pm.valid) return;
+        store_out<OUT>(L, pm, 0.0f, 0.0f, 0.0f);
+        if (COUNT && L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = 0;
+        return;
+    }
+    const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
+    const bool culled = bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1;  // wave-uniform: this wave holds only misses
+    RayState r;
+    r.t = 0.0f; r.t1 = 0.0f; r.dt = 1.0f; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
+    r.A = 0.0f; r.Gr = r.Gg = r.Gb = 0.0f; r.out = 0;
+    bool hit = false;
+    if (pm.valid && !culled) {
+        // --- ray: SURVEY A.1 step 1, as raymarch_naive_kernel ---
+        float fxp = (float)pm.x + 0.5f, fyp = (float)pm.y + 0.5f;
+        float ndcx = (2.0f * fxp) / (float)L.W - 1.0f;
+        float ndcy = 1.0f - (2.0f * fyp) / (float)L.H;
+        float q[4];
+        mat4_mul_vec4(fv.inv_proj, ndcx, ndcy, 1.0f, 1.0f, q);
+        const float eye[3] = {fv.eye[0], fv.eye[1], fv.eye[2]};
+        float dir[3] = {q[0] / q[3] - eye[0], q[1] / q[3] - eye[1], q[2] / q[3] - eye[2]};
+        normalize3(dir[0], dir[1], dir[2]);
+        float t0, t1;
+        intersect_box(eye, dir, 0.0f, 1.0f, t0, t1);
+        if (!(t0 > t1)) {  // :91-93
+            t0 = fmaxf(t0, 0.0f);  // :94
+            const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
+            float dtx = 1.0f / (fnx * fabsf(dir[0]));
+            float dty = 1.0f / (fny * fabsf(dir[1]));
+            float dtz = 1.0f / (fnz * fabsf(dir[2]));
+            const float dt = L.dt_scale * fminf(dtx, fminf(dty, dtz));  // :97-99
+            r.t = t0; r.t1 = t1; r.dt = dt;
+            r.px = eye[0] + t0 * dir[0]; r.py = eye[1] + t0 * dir[1]; r.pz = eye[2] + t0 * dir[2];  // :100
+            r.sx = dir[0] * dt; r.sy = dir[1] * dt; r.sz = dir[2] * dt;  // :118
+            hit = true;
+        }
+    }
+    // The group's major axis and direction of travel, by majority of its rays: nine counts per wave, summed in LDS.
+    extern __shared__ unsigned char stage_win[];
+    int *const ex = reinterpret_cast<int *>(stage_win);
+    if (threadIdx.x < 16u) ex[kGroupAccI + threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const float cs3[3] = {r.sx * (float)V.nx, r.sy * (float)V.ny, r.sz * (float)V.nz};  // cells per step, signed
+        const float ax = fabsf(cs3[0]), ay = fabsf(cs3[1]), az = fabsf(cs3[2]);
+        const int mj = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        const bool alive0 = hit && r.t < r.t1;
+        int cnt[9];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            cnt[k] = __popcll(__ballot(hit && mj == k));
+            cnt[3 + k] = __popcll(__ballot(alive0 && cs3[k] > 0.0f));
+            cnt[6 + k] = __popcll(__ballot(alive0 && cs3[k] < 0.0f));
+        }
+        if (lane == 0u) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) if (cnt[k]) atomicAdd(ex + kGroupAccI + k, cnt[k]);
+        }
+    }
+    __syncthreads();
+    const int c0 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 0]), c1 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 1]), c2 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 2]);
+    Census cs;
+    if (c0 + c1 + c2 != 0) {  // group-uniform
+        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
+        const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
+        const uint32_t copy = D.copy_of_major[major];
+        // (the S axis of copy k is axis k: the direction of travel is counted on that axis)
+        const bool dir_up = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 3 + copy]) >= __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 6 + copy]);
+        if (wave == 0u && lane < 16u) {  // both sets of the round accumulators at their neutral values
+            const uint32_t k = lane & 7u;
+            ex[kGroupAccB + lane] = (k == 0u || k > 4u) ? 0 : ((k & 1u) ? 0x7fffffff : (int)0x80000000);
+            if (lane < 4u) ex[kGroupAccS + lane] = (lane & 1u) == 0u ? 0 : (dir_up ? 0x7fffffff : (int)0x80000000);
+        }
+        __syncthreads();
+        if (copy == 0u) march_staged_group_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane, wave, dir_up);
+        else if (copy == 1u) march_staged_group_perm<VOL, 1, COUNT>(V, D, r, hit, cs, lane, wave, dir_up);
+        else march_staged_group_perm<VOL, 2, COUNT>(V, D, r, hit, cs, lane, wave, dir_up);
+    }
+    if (!pm.valid) return;
+    float Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
+    if (hit) {
+        Cr = linear_to_srgb(fmaf(0.5f, r.Gr, 0.5f * r.A));  // :121-123
+        Cg = linear_to_srgb(fmaf(0.5f, r.Gg, 0.5f * r.A));
+        Cb = linear_to_srgb(fmaf(0.5f, r.Gb, 0.5f * r.A));
+    }
+    store_out<OUT>(L, pm, Cr, Cg, Cb);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 2u) ? cs.n_fb : ((L.debug_flags & 1u) ? cs.n_look : cs.n_iter);
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)cs.n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)cs.n_samp);
+            atomicAdd(&L.counters[2], (unsigned long long)cs.w_outer);   // rounds (per wave)
+            atomicAdd(&L.counters[3], (unsigned long long)cs.w_inner);   // rounds served from global memory
+            atomicAdd(&L.counters[4], (unsigned long long)cs.w_sample);  // sum of T over rounds
             atomicAdd(&L.counters[5], (unsigned long long)cs.n_look);
         }
     }
