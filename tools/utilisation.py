@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("C2 headline: skip march, 64 orbit frames per launch", "default", "raymarch_naive_kernel<3, true, false, 1, false>", "raymarch_naive_kernelILi3ELb1ELb0ELi1ELb0E", None),
     ("C2 fog, dense march, 8 frames per launch", "fogbatch", "raymarch_naive_kernel<3, false, false, 1, false>", "raymarch_naive_kernelILi3ELb0ELb0ELi1ELb0E", 88),
-    ("C5: staged u8, 3840x2160, single frame", "c5", "raymarch_staged_kernel<10, 1, false>", "raymarch_staged_kernelILi10ELi1ELb0E", 50),
+    ("C5: staged u8, 3840x2160, single frame (one window per 256-thread group)", "c5", "raymarch_staged_group_kernel<10, 1, false>", "raymarch_staged_group_kernelILi10ELi1ELb0E", 50),
     ("C4: staged f16, 1920x1080, single frame", "c4", "raymarch_staged_kernel<11, 1, false>", "raymarch_staged_kernelILi11ELi1ELb0E", 50),
     ("compute twin (16-byte records), xor 1280x720, single frame", "xor", "raymarch_compute_records_kernel<1, false>", "raymarch_compute_records_kernelILi1ELb0E", 76),
     ("C3: procedural, 1920x1080, single frame", "c3", "raymarch_procedural_kernel<1, false>", "raymarch_procedural_kernelILi1ELb0E", None),
