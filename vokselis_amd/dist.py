@@ -290,7 +290,12 @@ class BatchTileRenderer:
             cams = cams + [cams[-1]] * (self.batch - len(cams))
         if self._used[s]:
             self.march_stream.wait_event(self.moved[s])  # the set's previous gather has read its tiles
-        bid, act = render_batch(self.ctx, self.pipe, cams, self.send[s].data_ptr(), tile_size=self.ts, rank=self.rank, nranks=self.world,
+        # Rank 0's share of a gather to rank 0 sits at the very start of the receive buffer whatever the active-slot count turns out to be: it
+        # marches straight into it (vk_gather_tiles then finds send == its own segment and copies nothing -- at a world of one that copy was
+        # the whole frame's tiles, 2.3 us per C2 frame).  The un-tile of this set's previous batch has read recv[s] on this stream already.
+        in_place = self.transport == "rccl" and self.rank == 0 and self.is_root and not self.rotate
+        send_ptr = self.recv[s].data_ptr() if in_place else self.send[s].data_ptr()
+        bid, act = render_batch(self.ctx, self.pipe, cams, send_ptr, tile_size=self.ts, rank=self.rank, nranks=self.world,
                                 compact=True, slot_capacity=self.cap)
         self.marched[s].record(self.march_stream)
         # the gather of this batch, on the communication stream
@@ -301,7 +306,7 @@ class BatchTileRenderer:
         if self.transport == "rccl":
             self.comm_stream.wait_event(self.marched[s])
             recv_ptr = self.recv[s].data_ptr() if mine else None
-            N.check(self.ctx.handle, N.lib().vk_gather_tiles(self.ctx.handle, C.c_void_p(self.send[s].data_ptr()), C.c_void_p(recv_ptr), n_px, root,
+            N.check(self.ctx.handle, N.lib().vk_gather_tiles(self.ctx.handle, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), n_px, root,
                                                             C.c_void_p(self.comm_stream.cuda_stream)))
             self.moved[s].record(self.comm_stream)
         else:
