@@ -804,7 +804,9 @@ static void launch_packed(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
 // per SIMD) and 20 KiB (2): C5 from far away 5.83 -> 3.5 ms, from close by 38.4 -> 34.1 ms against a fixed 8 KiB.
 static uint32_t staged_cap_auto(const vk_ctx *ctx, const float *cam, bool u8, uint32_t *slab_cells) {
     const uint32_t fallback = u8 ? 6144u : 10240u;
-    *slab_cells = u8 ? 6u : 8u;
+    // the slab search's upper limit: the budget decides the thickness, this only bounds the search (6 / 8 cells until round 3 cut slabs short that
+    // would have fitted: C4 1.855 -> 1.78 ms at 16-24, C5 10.0 -> 9.76 at 16; tools/staged_group.py, profiles/r03_staged_group.txt)
+    *slab_cells = u8 ? 16u : 24u;
     if (!cam) return fallback;
     const float *m = cam + 20;
     const double W = ctx->width, H = ctx->height;
@@ -864,7 +866,7 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     const bool group = (L.ts & 15u) == 0u && (ctx->stage_group == 1u || (ctx->stage_group == 2u && !ctx->stage_cap_bytes &&
                                                                                  (VOL == VOL_S8U8 ? cap_auto <= 6400u : (L.frames != nullptr && L.n_frames >= 4u && cap_auto <= 16384u))));
     if (group) {
-        if (!ctx->stage_slab_cells) D.slab_cells = std::min(2u * D.slab_cells, 32u);  // four waves' LDS hold a slab about twice as thick
+        if (!ctx->stage_slab_cells) D.slab_cells = std::max(D.slab_cells, 24u);  // four waves' LDS hold a slab about twice as thick
         const uint32_t lds = std::min(D.cap_bytes * kGroupWaves, 65536u) & ~15u;  // four waves' LDS, less the exchange block
         D.cap_bytes = lds - kGroupExchBytes;
         const uint32_t groups = (grid + kGroupWaves - 1u) / kGroupWaves;
