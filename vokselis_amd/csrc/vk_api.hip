@@ -37,7 +37,7 @@ struct vk_ctx {
     uint32_t stage_group = 2;    // staged march: one LDS window per 256-thread group of four waves (vk_staged.hpp: raymarch_staged_group_kernel): 0 never, 1 always, 2 where it pays (launch_staged)
     uint32_t frame_runs = 1;     // batched launches: every XCD marches a run of consecutive frames of a tile position (0: frames x, x + 8, ... as in round 2)
     uint32_t stage_grow_every = 0;  // slab search: try one cell above the last fit every n-th round (0: 4 for u8, 1 for f16; tools/staged_grow.py)
-    uint32_t stage_row_pad = 0;  // odd LDS row pitch of the staged window (experiment: tools/staged_row_pad.py)
+    uint32_t stage_row_pad = 2;  // odd LDS row pitch of the staged window: 0 never, 1 always, 2 (default) with group windows on u8 volumes (launch_staged)
     uint8_t *dist = nullptr;
     uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
     size_t vol_bytes = 0;
@@ -851,7 +851,7 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     const uint32_t cap_auto = staged_cap_auto(ctx, cam, VOL == VOL_S8U8, &slab_auto);
     D.cap_bytes = std::min(std::max((ctx->stage_cap_bytes ? ctx->stage_cap_bytes : cap_auto) & ~15u, 1024u), 65536u);
     D.slab_cells = std::min(std::max(ctx->stage_slab_cells ? ctx->stage_slab_cells : slab_auto, 1u), 32u);
-    D.row_pad = ctx->stage_row_pad ? 1u : 0u;
+    D.row_pad = ctx->stage_row_pad == 1u ? 1u : 0u;
     // u8 (at the issue-slot limit): every 4th round -- C5 10.40 -> 10.12 ms, other views +-1 %; f16 (waiting on fills, not on slots): every round
     D.grow_every = ctx->stage_grow_every ? ctx->stage_grow_every : (VOL == VOL_S8U8 ? 4u : 1u);
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
@@ -866,6 +866,10 @@ static void launch_staged(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V,
     const bool group = (L.ts & 15u) == 0u && (ctx->stage_group == 1u || (ctx->stage_group == 2u && !ctx->stage_cap_bytes &&
                                                                                  (VOL == VOL_S8U8 ? cap_auto <= 6400u : (L.frames != nullptr && L.n_frames >= 4u && cap_auto <= 16384u))));
     if (group) {
+        // An odd row pitch (in 16-byte pieces) spreads the window rows of neighbouring pixel rows over the LDS banks.  Per wave it cost C5 4 % (a
+        // padded piece per row out of 5 KiB); in a group's window the pad is a smaller share and four waves' taps collide more: C5 9.93 -> 9.53 ms,
+        // the diagonal view -3.5 %, four orbit frames per launch 9.19 -> 8.91, axis-aligned +2 %, close-up +-0 (profiles/r03_staged_group.txt).
+        if (ctx->stage_row_pad == 2u && VOL == VOL_S8U8) D.row_pad = 1u;
         if (!ctx->stage_slab_cells) D.slab_cells = std::max(D.slab_cells, 24u);  // four waves' LDS hold a slab about twice as thick
         const uint32_t lds = std::min(D.cap_bytes * kGroupWaves, 65536u) & ~15u;  // four waves' LDS, less the exchange block
         D.cap_bytes = lds - kGroupExchBytes;
