@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         r.px = px; r.py = py; r.pz = pz; r.sx = sx; r.sy = sy; r.sz = sz;
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
-        if (L.debug_flags & 16u) set_wave_priority(true, t0, t1, dt, fmaxf(fnx, fmaxf(fny, fnz)) / L.dt_scale);
+        // (not in the skip kernels: a ray's nominal length says little about its work there -- C2 at 64 orbit frames per launch 0.06509 -> 0.06467 ms without)
+        if (!SKIP && (L.debug_flags & 16u)) set_wave_priority(true, t0, t1, dt, fmaxf(fnx, fmaxf(fny, fnz)) / L.dt_scale);
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
         else if constexpr (SKIP) {
             if (L.debug_flags & 4u) {
