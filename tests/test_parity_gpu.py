@@ -1042,6 +1042,15 @@ def test_error_behaviour(V, O, cameras, golden_volumes):
         pipe.record(ctx, (0, 0, 0, 0))  # empty tile is a no-op
         info = ctx.get_info()
         assert info["gfx950"] and info["compute_units"] == 256
+        # the wire format of a partition's tiles: an enum of two, 16 or 12 bytes per rgba32f pixel
+        with pytest.raises(V.VokselisError, match="VK_WIRE"):
+            ctx.set_wire(5)
+        assert ctx.wire_pixel_bytes == 16
+        ctx.set_wire(V.WIRE_RGB)
+        assert ctx.wire_pixel_bytes == 12
+        ctx.set_wire(V.WIRE_RGBA)
+        with pytest.raises(V.VokselisError, match="trip_log_cap"):
+            ctx.set_param("trip_log_cap", 12)  # (a multiple of 8)
     finally:
         ctx.close()
 
