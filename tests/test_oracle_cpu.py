@@ -286,3 +286,40 @@ def test_literal_wgsl_yardstick(O):
     L = O.lib()
     xs = np.linspace(0, 255, 50001, dtype=np.float32)
     assert max(abs(L.vo_transfer_alpha(float(x), 1) - L.vo_transfer_alpha_literal(float(np.float32(x) / np.float32(255.0)))) for x in xs) <= 2.5e-7
+
+
+def test_volume_png_pin(O):
+    """The one reference-held pin (oracle/volume_png.py): xor.wgsl generator at t = 0 -> raycast_compute.wgsl at 1280x720 ->
+    present.wgsl to the capture's 958x1050, at the camera fitted to the reference's `volume.png`.  The capture itself travels
+    as a blurred 1/8-scale fixture; where /root/reference exists the fixture is re-derived from the file."""
+    import os
+
+    from oracle import volume_png as VP
+
+    pin = VP.load_pin()
+    cap = pin["capture_blur_ds"].astype(np.float32)
+    if os.path.exists(VP.REF_PNG):
+        from PIL import Image
+
+        png = np.array(Image.open(VP.REF_PNG).convert("RGB"))
+        assert png.shape == (VP.WIN_H, VP.WIN_W, 3)
+        assert (png[0, 0] == VP.BACKGROUND).all() and (png[-1, -1] == VP.BACKGROUND).all()
+        assert np.abs(VP.blurred_ds(png) - cap).max() <= 0.13  # f16 storage of values <= 255
+    zoom, pitch, yaw = (float(v) for v in pin["orbit"])
+    assert VP.camera(zoom, pitch, yaw) == pin["camera"].tobytes()
+    frame = VP.render_oracle(zoom, pitch, yaw)
+    # background: clear colour (0.023, 0.02, 0.02) -> ACES -> branch-free sRGB -> 8 bit, exactly the capture's
+    assert (frame[0, 0, :3] == VP.BACKGROUND).all() and (frame[-1, -1, :3] == VP.BACKGROUND).all() and (frame[..., 3] == 255).all()
+    m = VP.metrics(frame, cap)
+    VP.check(m)
+    assert abs(m["corr"] - float(pin["corr"])) < 5e-3 and abs(m["mean_abs"] - float(pin["mean_abs"])) < 0.05
+    # the committed frame is this frame (libm's powf may move a pixel by one step between machines)
+    want = VP.load_oracle_frame()
+    d = np.abs(frame[..., :3].astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    # the example's own initial camera (examples/xor/main.rs:273-279) shows the same blob 1.5x smaller: the fit moved zoom, not shape
+    f0 = VP.render_oracle(3.0, -0.5, 1.0)
+    b0 = VP._bbox(VP.blurred_ds(f0))
+    b1 = VP._bbox(VP.blurred_ds(frame))
+    ratio = (b1[3] - b1[2]) / (b0[3] - b0[2])
+    assert 1.35 < ratio < 1.75, ratio
