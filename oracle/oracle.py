@@ -51,13 +51,18 @@ class RenderArgs(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    src = os.path.join(_HERE, "vokselis_oracle.c")
-    hdr = os.path.join(_HERE, "vokselis_oracle.h")
-    stale = (not os.path.exists(_SO)) or any(
-        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, hdr)
-    )
-    if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("vokselis_oracle.c", "vokselis_oracle.h", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    key, stamp = h.hexdigest()[:16], _SO + ".stamp"
+    # keyed on the sources' content (mtimes do not survive a sync to another box)
+    if force or not os.path.exists(_SO) or not os.path.exists(stamp) or open(stamp).read().strip() != key:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(key + "\n")
     return _SO
 
 

@@ -1,4 +1,4 @@
-// fake_rccl.cpp -- TEST INFRASTRUCTURE: the nine RCCL entry points libvokselis_hip.so binds (vk_api.hip: RcclApi),
+// fake_rccl.cpp -- TEST INFRASTRUCTURE: the nine RCCL entry points libvokselis_hip.so binds (vk_comm.hip: RcclApi),
 // implemented inside ONE process with stream-ordered hipMemcpyAsync, so that the N > 1 branches of vk_gather_tiles and
 // vk_group_render execute on a box with a single GPU.  Loaded only when the environment
 // names it (VK_RCCL_LIB=tests/_build/libfake_rccl.so); the product never links it.

@@ -20,7 +20,7 @@ def _free_port():
 
 
 def test_weighted_deal_is_a_bijection():
-    """deal_pos / deal_owner (Python mirror of vk_kernels.hpp): every position has exactly one (rank, slot), slots are
+    """deal_pos / deal_owner (Python mirror of vk_common.hpp): every position has exactly one (rank, slot), slots are
     dense per rank, the root's share shrinks to (k-1)/k of a peer's."""
     from vokselis_amd import dist as D
 
@@ -135,15 +135,17 @@ def test_bench_window_rule():
 
 def test_fake_rccl_builds_and_exports_the_bound_symbols():
     """The single-process stand-in for RCCL the gpu suite binds through VK_RCCL_LIB (tests/fake_rccl.cpp) builds here and
-    exports the nine entry points vk_api.hip resolves (no call without a GPU)."""
+    exports the nine entry points vk_comm.hip resolves (no call without a GPU)."""
     import ctypes as C
 
     import __graft_entry__ as g
 
+    if not (os.path.isdir("/opt/rocm/include/hip") and os.path.exists("/opt/rocm/lib/libamdhip64.so")):
+        pytest.skip("no ROCm headers / runtime on this box: the stand-in links libamdhip64")
     lib = C.CDLL(g.build_fake_rccl())
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
                  "ncclGetErrorString", "fake_rccl_stats", "fake_rccl_unmatched"):
         assert getattr(lib, name) is not None
-    src = open(os.path.join(ROOT, "vokselis_amd", "csrc", "vk_api.hip")).read()
+    src = open(os.path.join(ROOT, "vokselis_amd", "csrc", "vk_comm.hip")).read()
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
         assert 'sym("%s")' % name in src, name

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of a kernel's loops, priced with the measured issue-cost table.
 
-  python tools/isa_hist.py <kernel-name-regex> [--src vokselis_amd/csrc/vk_api.hip] [--blocks]
+  python tools/isa_hist.py <kernel-name-regex> [--src vokselis_amd/csrc/vk_launch_cells.hip] [--blocks]
 
 Compiles the translation unit to gfx950 assembly (hipcc -S, the product's own flags), finds the kernel whose mangled
 name matches, and prints for every loop (the compiler's "Loop Header: Depth=n" annotations) the count of vector,
@@ -75,11 +75,16 @@ def classify(op: str) -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("kernel")
-    ap.add_argument("--src", default=os.path.join(ROOT, "vokselis_amd", "csrc", "vk_api.hip"))
-    ap.add_argument("--asm", default="/tmp/isa/vk_api.s", help="reuse this assembly file when newer than the sources")
+    ap.add_argument("--src", default=None, help="translation unit that instantiates the kernel (default: chosen from the kernel's name)")
+    ap.add_argument("--asm", default=None, help="reuse this assembly file when newer than the sources")
     ap.add_argument("--blocks", action="store_true", help="print every basic block, not just the loops")
     ap.add_argument("--dump", action="store_true", help="print the instructions of the loops")
     a = ap.parse_args()
+    if a.src is None:  # the march kernels are instantiated by three translation units (vokselis_amd/csrc/vk_ctx.hpp)
+        tu = "vk_launch_staged.hip" if "staged" in a.kernel else ("vk_launch_compute.hip" if re.search("compute|procedural", a.kernel) else "vk_launch_cells.hip")
+        a.src = os.path.join(ROOT, "vokselis_amd", "csrc", tu)
+    if a.asm is None:
+        a.asm = "/tmp/isa/%s.s" % os.path.splitext(os.path.basename(a.src))[0]
     deps = [a.src] + [os.path.join(os.path.dirname(a.src), f) for f in os.listdir(os.path.dirname(a.src)) if f.endswith(".hpp")]
     if not os.path.exists(a.asm) or any(os.path.getmtime(d) > os.path.getmtime(a.asm) for d in deps):
         os.makedirs(os.path.dirname(a.asm), exist_ok=True)

@@ -1,4 +1,4 @@
-"""HBM traffic per launch of the headline kernel, per launch shape, from the PMC passes of tools/prof_r3.sh:
+"""HBM traffic per launch of the headline kernel, per launch shape, from the PMC passes of tools/prof.sh:
 tools/pmc_traffic.py <gpurun_out/prof_r3> <config>  ->  the <config> entry of profiles/r03_pmc_traffic.json on stdout.
 
 FETCH_SIZE and WRITE_SIZE are collected in separate rocprofv3 runs (they do not fit one pass: MI355X_MICROARCH.md, rocprofv3
@@ -47,7 +47,7 @@ for shape in sorted(os.listdir(root)):
             if KERNEL in r["Name"] and "true>(vk::LaunchDesc" not in r["Name"].replace(" ", ""):
                 stats = {"kernel_avg_ns_rocprofv3": float(r["AverageNs"]), "kernel_min_ns_rocprofv3": float(r["MinNs"]), "kernel_calls_rocprofv3": int(r["Calls"])}
     out["per_frames_per_launch"][str(fpl)] = {
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/prof_r3.sh, shape '%s': `python3 bench.py --no-extras --no-cpu-baseline --headline-only%s`), "
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/prof.sh, shape '%s': `python3 bench.py --no-extras --no-cpu-baseline --headline-only%s`), "
                   "means over the run's %d / %d launches of the production %s instance" % (shape, "" if shape == "default" else " --steps 20 --warmup 5", nf, nw, KERNEL),
         "frames_per_launch": fpl, "cameras": j["config"].get("cameras", ""),
         "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,

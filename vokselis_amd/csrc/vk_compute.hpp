@@ -1,0 +1,261 @@
+// vk_compute.hpp -- COMPUTE_NEAREST (raycast_compute.wgsl:62-144) on the bricked record layout and on the two dense volumes,
+// and PROCEDURAL.  Included by vk_launch_compute.hip only.
+#pragma once
+
+#include "vk_common.hpp"
+#include "vk_xor.hpp"
+
+namespace vk {
+
+// Same arithmetic as raymarch_compute_kernel below (raycast_compute.wgsl:62-131), one 16-byte record
+// per step, software-pipelined: p = eye + t*dir does not depend on the loads, so the next step's
+// record is requested before this step is shaded.  A lone wave of this mode used to pay a full
+// cache-miss latency per step (<= 346 dependent steps per ray).
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const LaunchDesc L, const VolumeDesc V) {
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;
+    const uint32_t lane = threadIdx.x;
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
+    extern __shared__ uint32_t pair_lut[];
+    {
+        const uint32_t n4 = pair_lut_entries(V.nx, V.ny, V.nz) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(V.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(pair_lut);
+        for (uint32_t e = lane; e < n4; e += 64u) dst[e] = src[e];
+        __syncthreads();
+    }
+    if (!pm.valid) return;
+
+    float dimx = (float)L.W, dimy = (float)L.H;
+    float aspect_ratio = dimy / dimx;
+    float scx = 2.0f * (float)pm.x / dimx - 1.0f;
+    float scy = 2.0f * (float)pm.y / dimy - 1.0f;
+    scy = scy * -aspect_ratio;
+    float vp[4], vt[4];
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
+    float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
+    normalize3(dir[0], dir[1], dir[2]);
+
+    const float clr[3] = {0.023f, 0.02f, 0.02f};  // :118, clear alpha 0
+    float C[3] = {clr[0], clr[1], clr[2]};
+    uint32_t n_iter = 0;
+    float t0, t1;
+    intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
+    if (t0 < t1) {  // :123
+        t0 = fmaxf(t0, 0.0f);
+        float A = 0.1f;  // get_col2 :63
+        const float bsx = (float)V.nx, bsy = (float)V.ny, bsz = (float)V.nz;
+        float dtx = 1.0f / (bsx * fabsf(dir[0]));
+        float dty = 1.0f / (bsy * fabsf(dir[1]));
+        float dtz = 1.0f / (bsz * fabsf(dir[2]));
+        const float dt = L.dt_scale * fmaxf(fminf(dtx, fminf(dty, dtz)), 0.01f);  // :66-68
+        const float hbx = bsx / 2.0f, hby = bsy / 2.0f, hbz = bsz / 2.0f;
+        float l1x = -2.0f, l1y = -2.0f, l1z = -1.0f, l2x = 1.0f, l2y = 1.0f, l2z = -1.0f;
+        normalize3(l1x, l1y, l1z);
+        normalize3(l2x, l2y, l2z);
+        const uint32_t *luty = pair_lut + (V.nx + 2u * kPairPad), *lutz = pair_lut + (V.nx + V.ny + 4u * kPairPad);
+        const __amdgpu_buffer_rsrc_t recs = cell_buffer(V.data, (uint32_t)V.max_off + 16u);
+        struct Req { float px, py, pz; u32x4_t r; };
+        auto request = [&](float t) -> Req {
+            Req q;
+            q.px = eye[0] + t * dir[0]; q.py = eye[1] + t * dir[1]; q.pz = eye[2] + t * dir[2];
+            // ivec3 truncation (:75); |p| stays within a few steps of the box, so the conversions are in range
+            const int ix = (int)((q.px + 1.0f) * hbx), iy = (int)((q.py + 1.0f) * hby), iz = (int)((q.pz + 1.0f) * hbz);
+            const uint32_t off = pair_lut[ix + (int)kPairPad] + luty[iy + (int)kPairPad] + lutz[iz + (int)kPairPad];
+            q.r = __builtin_amdgcn_raw_buffer_load_b128(recs, (int)off, 0, 0);
+            return q;
+        };
+        float t = t0;
+        Req cur = request(t), nxt = cur;
+        for (;;) {  // :69, entered with t < t1
+            const float tn = t + dt;
+            nxt = request(tn);
+            const float px = cur.px, py = cur.py, pz = cur.pz;
+            const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
+            float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
+            float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
+            n_iter++;
+            // The shader's literal expressions (kept word for word in raymarch_compute_kernel below, which the tests hold
+            // this kernel to bit for bit) carry terms that are zero for every finite record: dot((0,-1,0), n) is -n.y,
+            // mix(shade, bl * (0,0,0.6), 0.2) has zero red and green contributions from bl, and clear.rgb * clear.a * (1 - a)
+            // is 0 * (1 - a).  IEEE arithmetic forbids the compiler to drop them (0 * x is NaN for an infinite x); with finite
+            // taps they only ever add a zero to a non-zero accumulator, so leaving them out changes no bit: 15 of the step's
+            // 85 instructions.  A volume with infinities or NaNs renders differently from the literal form.
+            float sh = fmaxf(0.0f, -n1);
+            float va = (vc3 * vc3) * vc3;
+            va = smoothstepf(0.0f, 0.7f, va);
+            float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
+            float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
+            float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
+            float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
+            float sh0 = sh * (1.0f - 0.2f);
+            float sh1 = sh0;
+            float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
+            float w = (1.0f - A) * va;
+            C[0] = C[0] + w * col0 * sh0;
+            C[1] = C[1] + w * col1 * sh1;
+            C[2] = C[2] + w * col2 * sh2;
+            A = A + w;
+            if (A >= 0.95f) break;
+            t = tn;
+            if (!(t < t1)) break;
+            cur = nxt;
+        }
+        asm volatile("" ::"v"(nxt.r));  // the last request is consumed on the exit path too (keeps it ahead of the shading)
+    }
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+        }
+    }
+}
+
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L, const VolumeDesc V) {
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;
+    const uint32_t lane = threadIdx.x;
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, lane);
+    if (!pm.valid) return;
+
+    // render(): raycast_compute.wgsl:99-116 -- no half-pixel offset, y scaled by -H/W
+    float dimx = (float)L.W, dimy = (float)L.H;
+    float aspect_ratio = dimy / dimx;
+    float scx = 2.0f * (float)pm.x / dimx - 1.0f;
+    float scy = 2.0f * (float)pm.y / dimy - 1.0f;
+    scy = scy * -aspect_ratio;
+    float vp[4], vt[4];
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
+    float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
+    normalize3(dir[0], dir[1], dir[2]);
+
+    const float clr[3] = {0.023f, 0.02f, 0.02f};  // :118, clear alpha 0
+    float C[3] = {clr[0], clr[1], clr[2]};
+    uint32_t n_iter = 0;
+    float t0, t1;
+    intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
+    if (t0 < t1) {  // :123
+        t0 = fmaxf(t0, 0.0f);
+        float A = 0.1f;  // get_col2 :63
+        const float bsx = (float)V.nx, bsy = (float)V.ny, bsz = (float)V.nz;
+        float dtx = 1.0f / (bsx * fabsf(dir[0]));
+        float dty = 1.0f / (bsy * fabsf(dir[1]));
+        float dtz = 1.0f / (bsz * fabsf(dir[2]));
+        const float dt = L.dt_scale * fmaxf(fminf(dtx, fminf(dty, dtz)), 0.01f);  // :66-68
+        const float hbx = bsx / 2.0f, hby = bsy / 2.0f, hbz = bsz / 2.0f;
+        float l1x = -2.0f, l1y = -2.0f, l1z = -1.0f, l2x = 1.0f, l2y = 1.0f, l2z = -1.0f;
+        normalize3(l1x, l1y, l1z);
+        normalize3(l2x, l2y, l2z);
+        const uint2 *den = reinterpret_cast<const uint2 *>(V.data);
+        const uint2 *nrm = reinterpret_cast<const uint2 *>(V.data2);
+        for (float t = t0; t < t1; t = t + dt) {  // :69
+            float px = eye[0] + t * dir[0], py = eye[1] + t * dir[1], pz = eye[2] + t * dir[2];
+            int ix = (int)((px + 1.0f) * hbx), iy = (int)((py + 1.0f) * hby), iz = (int)((pz + 1.0f) * hbz);
+            // textureLoad with naga's Unchecked bounds policy: this build defines OOB as zeros (A.2)
+            bool inb = ix >= 0 && iy >= 0 && iz >= 0 && ix < (int)V.nx && iy < (int)V.ny && iz < (int)V.nz;
+            uint2 dv = make_uint2(0, 0), nv = make_uint2(0, 0);
+            if (inb) {
+                size_t idx = (size_t)ix + (size_t)V.nx * ((size_t)iy + (size_t)V.ny * (size_t)iz);
+                dv = den[idx];
+                nv = nrm[idx];
+            }
+            float vc0 = h2f(dv.x & 0xffffu), vc1 = h2f(dv.x >> 16), vc2 = h2f(dv.y & 0xffffu), vc3 = h2f(dv.y >> 16);
+            float n0 = h2f(nv.x & 0xffffu), n1 = h2f(nv.x >> 16), n2 = h2f(nv.y & 0xffffu);
+            n_iter++;
+            float sh = fmaxf(0.0f, (0.0f * n0 + -1.0f * n1) + 0.0f * n2);
+            float va = (vc3 * vc3) * vc3;
+            va = smoothstepf(0.0f, 0.7f, va);
+            float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
+            float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
+            float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
+            float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
+            float sh0 = sh * (1.0f - 0.2f) + (bl * 0.0f) * 0.2f;
+            float sh1 = sh0;
+            float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
+            float w = (1.0f - A) * va;
+            C[0] = (C[0] + w * col0 * sh0) + clr[0] * 0.0f * (1.0f - va);
+            C[1] = (C[1] + w * col1 * sh1) + clr[1] * 0.0f * (1.0f - va);
+            C[2] = (C[2] + w * col2 * sh2) + clr[2] * 0.0f * (1.0f - va);
+            A = A + w * (1.0f - 0.0f);
+            if (A >= 0.95f) break;
+        }
+    }
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+        }
+    }
+}
+
+// ---- PROCEDURAL: the compute twin's ray and march with the texel loads replaced by the xor
+// example's density function at the sample position, noise_volume(p / 2) (shaders/xor.wgsl:55-61), colour =
+// density.rgb / 2, no normals -- mirrors pixel_procedural of the oracle operation for operation.  No volume,
+// no loads: 24 specified sines (f64 Cody-Waite, ~45 f64 operations each) and ~200 f32 flops per step.
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDesc L, float time) {
+    const uint32_t lb = logical_block(blockIdx.x);
+    if (lb >= L.n_blocks) return;
+    const FrameView fv = frame_view(L, lb);
+    const PixelMap pm = map_pixel(L, fv, threadIdx.x);
+    if (!pm.valid) return;
+    float dimx = (float)L.W, dimy = (float)L.H;
+    float aspect_ratio = dimy / dimx;
+    float scx = 2.0f * (float)pm.x / dimx - 1.0f;
+    float scy = 2.0f * (float)pm.y / dimy - 1.0f;
+    scy = scy * -aspect_ratio;
+    float vp[4], vt[4];
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 0.0f, 1.0f, vp);
+    mat4_mul_vec4(fv.inv_proj, scx, scy, 1.0f, 1.0f, vt);
+    const float eye[3] = {vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3]};
+    float dir[3] = {vt[0] / vt[3] - eye[0], vt[1] / vt[3] - eye[1], vt[2] / vt[3] - eye[2]};
+    normalize3(dir[0], dir[1], dir[2]);
+    float C[3] = {0.023f, 0.02f, 0.02f};
+    uint32_t n_iter = 0;
+    float t0, t1;
+    intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
+    if (t0 < t1) {
+        t0 = fmaxf(t0, 0.0f);
+        float A = 0.1f;
+        const float bs = 256.0f;
+        float dtx = 1.0f / (bs * fabsf(dir[0])), dty = 1.0f / (bs * fabsf(dir[1])), dtz = 1.0f / (bs * fabsf(dir[2]));
+        const float dt = L.dt_scale * fmaxf(fminf(dtx, fminf(dty, dtz)), 0.01f);
+        const float off1 = sin_spec(time * 1.0f) * 0.1f;
+        for (float t = t0; t < t1; t = t + dt) {
+            const float px = eye[0] + t * dir[0], py = eye[1] + t * dir[1], pz = eye[2] + t * dir[2];
+            float val, alpha;
+            xor_noise_volume(px * 0.5f, py * 0.5f, pz * 0.5f, off1, val, alpha);
+            n_iter++;
+            const float vc = val / 2.0f;
+            float va = (alpha * alpha) * alpha;
+            va = smoothstepf(0.0f, 0.7f, va);
+            const float w = (1.0f - A) * va;
+            C[0] = C[0] + w * vc; C[1] = C[1] + w * vc; C[2] = C[2] + w * vc;
+            A = A + w;
+            if (A >= 0.95f) break;
+            if (!(dt > 0.0f)) break;
+        }
+    }
+    store_out<OUT>(L, pm, C[0], C[1], C[2]);
+    if (COUNT) {
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
+        if (L.counters) {
+            atomicAdd(&L.counters[0], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+        }
+    }
+}
+
+}  // namespace vk

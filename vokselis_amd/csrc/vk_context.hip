@@ -1,0 +1,297 @@
+// vk_context.hip -- context lifetime, uniforms, backbuffer, read-back, counters, timers and tuning knobs of the C-ABI
+// (include/vokselis_hip.h).  gfx950 only; no CPU fallback: every entry point fails with VK_ERR_HIP / VK_ERR_NO_DEVICE when
+// the HIP runtime or the device is unavailable.
+#include "vk_ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace vk;
+
+thread_local std::string g_create_err;
+
+extern "C" {
+
+int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+uint32_t vk_dispatch_optimal(uint32_t len, uint32_t subgroup_size) {
+    if (subgroup_size == 0) return 0;
+    uint32_t padded = (subgroup_size - len % subgroup_size) % subgroup_size;
+    return (len + padded) / subgroup_size;
+}
+
+const char *vk_last_error(vk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int vk_ctx_create(int device_ordinal, vk_ctx **out) {
+    if (!out) return fail(nullptr, VK_ERR_INVALID, "vk_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, VK_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, VK_ERR_INVALID, "vk_ctx_create: device ordinal out of range");
+    vk_ctx *ctx = new (std::nothrow) vk_ctx();
+    if (!ctx) return fail(nullptr, VK_ERR_OOM, "vk_ctx_create: host allocation failed");
+    ctx->device = device_ordinal;
+    auto bail = [&](hipError_t err, const char *what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return fail(nullptr, VK_ERR_HIP, msg);
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string msg = std::string("device is ") + ctx->prop.gcnArchName + ", this library carries gfx950 code only";
+        delete ctx;
+        return fail(nullptr, VK_ERR_NO_DEVICE, msg);
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&ctx->counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(counters)");
+    *out = ctx;
+    return VK_OK;
+}
+
+int vk_ctx_destroy(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
+    free_volume(ctx);
+    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
+    if (ctx->steps) (void)hipFree(ctx->steps);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->rgba8) (void)hipFree(ctx->rgba8);
+    if (ctx->bgra8) (void)hipFree(ctx->bgra8);
+    if (ctx->trace) (void)hipFree(ctx->trace);
+    if (ctx->d_ring) (void)hipFree(ctx->d_ring);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+    for (auto &b : ctx->batch) { if (b.d) (void)hipFree(b.d); if (b.h) (void)hipHostFree(b.h); if (b.ev) (void)hipEventDestroy(b.ev); }
+    for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
+    for (hipEvent_t e : ctx->ring_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VK_OK;
+}
+
+int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VK_OK;
+}
+
+int vk_ctx_sync(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_device_info(vk_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *arch_is_gfx950,
+                   size_t *total_mem_bytes) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (name && name_cap) std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (arch_is_gfx950) *arch_is_gfx950 = std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) == 0;
+    if (total_mem_bytes) *total_mem_bytes = ctx->prop.totalGlobalMem;
+    return VK_OK;
+}
+
+// ---- uniforms ------------------------------------------------------------------------------------
+
+int vk_set_uniform(vk_ctx *ctx, const void *blob48) {
+    if (!ctx || !blob48) return fail(ctx, VK_ERR_INVALID, "vk_set_uniform: NULL argument");
+    std::memcpy(ctx->uniform, blob48, 48);  // read by neither fs_main nor get_col2
+    return VK_OK;
+}
+
+int vk_set_camera(vk_ctx *ctx, const void *blob144) {
+    if (!ctx || !blob144) return fail(ctx, VK_ERR_INVALID, "vk_set_camera: NULL argument");
+    std::memcpy(ctx->camera, blob144, 144);
+    for (int i = 0; i < 36; i++)
+        if (!std::isfinite(ctx->camera[i])) { ctx->have_camera = false; return fail(ctx, VK_ERR_INVALID, "camera blob has non-finite entries"); }
+    ctx->have_camera = true;
+    return VK_OK;
+}
+
+// ---- backbuffer ------------------------------------------------------------------------------------
+
+int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_format) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, VK_ERR_INVALID, "backbuffer size must be in [1, 32768]");
+    if (out_format != VK_OUT_RGBA32F && out_format != VK_OUT_RGBA16F) return fail(ctx, VK_ERR_INVALID, "unknown output format");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &b : ctx->batch) b.id = 0;  // batch ids held by the caller named tiles of the old shape
+    ctx->batch_key.clear();
+    for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
+    ctx->batch_retired.clear();
+    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
+    if (ctx->steps) (void)hipFree(ctx->steps);
+    ctx->backbuffer = nullptr;
+    ctx->steps = nullptr;
+    ctx->width = ctx->height = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->backbuffer, (size_t)width * height * px_bytes(out_format)));
+    ctx->width = width;
+    ctx->height = height;
+    ctx->out_format = out_format;
+    return vk_backbuffer_clear(ctx);
+}
+
+int vk_backbuffer_info(vk_ctx *ctx, uint32_t *width, uint32_t *height, int *out_format, void **device_ptr) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (width) *width = ctx->width;
+    if (height) *height = ctx->height;
+    if (out_format) *out_format = ctx->out_format;
+    if (device_ptr) *device_ptr = ctx->backbuffer;
+    return VK_OK;
+}
+
+// Device buffers for hosts without another allocator (the C++ host, a plain C consumer): frame batches, gather buffers.
+int vk_device_alloc(vk_ctx *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr || bytes == 0) return fail(ctx, VK_ERR_INVALID, "vk_device_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *ptr = nullptr;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? VK_ERR_OOM : VK_ERR_HIP, std::string("vk_device_alloc: ") + hipGetErrorString(e));
+    return VK_OK;
+}
+
+int vk_device_free(vk_ctx *ctx, void *ptr) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ptr));
+    return VK_OK;
+}
+
+int vk_device_download(vk_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+    if (!ctx || !dst_host || !src_device) return fail(ctx, VK_ERR_INVALID, "vk_device_download: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+// ---- results ------------------------------------------------------------------------------------
+
+int vk_readback(vk_ctx *ctx, void *dst, size_t row_pitch_bytes) {
+    if (!ctx || !dst) return fail(ctx, VK_ERR_INVALID, "vk_readback: NULL argument");
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "no backbuffer");
+    const size_t row = (size_t)ctx->width * px_bytes(ctx->out_format);
+    if (row_pitch_bytes < row) return fail(ctx, VK_ERR_INVALID, "row pitch smaller than a row");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, row_pitch_bytes, ctx->backbuffer, row, row, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_step_counts(vk_ctx *ctx, uint64_t *s_ref, uint64_t *s_sampled) {
+    if (!ctx) return VK_ERR_INVALID;
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s_ref) *s_ref = h[0];
+    if (s_sampled) *s_sampled = h[1];
+    return VK_OK;
+}
+
+int vk_simt_census(vk_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return fail(ctx, VK_ERR_INVALID, "vk_simt_census: NULL argument");
+    unsigned long long h[8] = {0};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; i++) out[i] = h[2 + i];
+    return VK_OK;
+}
+
+int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks) {
+    if (!ctx) return VK_ERR_INVALID;
+    ctx->want_trace = enable != 0;
+    if (!out) return VK_OK;
+    if (!ctx->trace || n_blocks > ctx->trace_blocks) return fail(ctx, VK_ERR_INVALID, "vk_debug_wave_trace: no trace of that size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->trace, n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VK_OK;
+}
+
+int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return VK_ERR_INVALID;
+    const std::string n(name);
+    if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
+    else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
+    else if (n == "trip_log_cap") { if (value < 0 || value > 4096 || ((uint32_t)value & 7u)) return fail(ctx, VK_ERR_INVALID, "trip_log_cap: a multiple of 8 up to 4096"); ctx->trip_log_cap = (uint32_t)value; }
+    else if (n == "stage_group") ctx->stage_group = (uint32_t)value;             // staged march: windows shared by the four waves of a group (tools/staged_group.py)
+    else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (tools/frame_runs.py)
+    else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
+    else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)
+    else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
+    else if (n == "walk_cap") ctx->walk_cap = (uint32_t)value;
+    else if (n == "walk_cap_all") ctx->walk_cap_all = (uint32_t)value;
+    else if (n == "order_rays") { ctx->order_rays = ctx->order_rays_batch = (uint32_t)std::min<double>(std::max<double>(value, 1), 8); ctx->batch_key.clear(); ctx->order_key.clear(); }
+    else if (n == "naive_lds_pad") ctx->naive_lds_pad = (uint32_t)value;          // experiments: caps the cell kernels' waves per SIMD
+    else if (n == "stage_copies_mask") ctx->stage_copies_mask = (uint32_t)value; // which brick copies to build (next upload)
+    else return fail(ctx, VK_ERR_INVALID, "vk_debug_set_param: unknown parameter " + n);
+    return VK_OK;
+}
+
+int vk_step_counts_reset(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    return VK_OK;
+}
+
+int vk_readback_steps(vk_ctx *ctx, uint32_t *dst) {
+    if (!ctx || !dst) return fail(ctx, VK_ERR_INVALID, "vk_readback_steps: NULL argument");
+    if (!ctx->steps) return fail(ctx, VK_ERR_INVALID, "no VK_RENDER_COUNT launch since the last resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_timer_begin(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    ctx->timing_open = true;
+    ctx->timing_done = false;
+    return VK_OK;
+}
+
+int vk_timer_end(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->timing_open) return fail(ctx, VK_ERR_INVALID, "vk_timer_end without vk_timer_begin");
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timing_open = false;
+    ctx->timing_done = true;
+    return VK_OK;
+}
+
+int vk_timer_elapsed_ms(vk_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return fail(ctx, VK_ERR_INVALID, "vk_timer_elapsed_ms: NULL argument");
+    if (!ctx->timing_done) return fail(ctx, VK_ERR_INVALID, "no completed timer bracket");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VK_OK;
+}
+
+
+}  // extern "C"

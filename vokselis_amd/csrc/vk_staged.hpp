@@ -23,23 +23,9 @@
 //  * The arithmetic on the taps is that of march() (LINEAR / 9^3 layouts): frames are bitwise equal.
 #pragma once
 
-#include "vk_kernels.hpp"
+#include "vk_march.hpp"
 
 namespace vk {
-
-constexpr int kStagePad = 8;
-
-struct StagedDesc {
-    const unsigned char *copy[3];  // copy[k]: SLOW axis k, FAST axis (k+1)%3, MID axis (k+2)%3 (nullptr: not built)
-    uint32_t copy_of_major[3];     // copy used by a wave whose rays' major axis is x / y / z
-    uint32_t nv[3];                // padded voxel extent per axis (multiple of 8, >= n + kStagePad + 2)
-    uint32_t npf[3];               // per copy: 16-byte pieces along its FAST axis
-    uint32_t nbm[3];               // per copy: bricks along its MID axis
-    uint32_t cap_bytes;            // LDS window capacity = dynamic LDS of the launch
-    uint32_t slab_cells;           // a round is a slab of at most this many cells along the wave's major axis
-    uint32_t grow_every;           // the slab search tries one cell above the last fit every grow_every-th round (>= 1)
-    uint32_t row_pad;              // 1: window rows of an even number of pieces carry one more (an odd row pitch, in pieces, spreads the rows of a wave over the LDS banks)
-};
 
 // floor(q / d) = umulhi(q, kMagic[d]) for q * d < 2^32, d in [2, 64]
 __device__ const uint32_t kStageMagic[65] = {
@@ -97,35 +83,6 @@ __device__ __forceinline__ int select_i32(unsigned long long mask, int a, int b)
     int r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
     return r;
-}
-
-// Dense voxels -> one staged copy.  One thread per 16-byte piece, pieces enumerated in storage order.
-template <bool U8>
-__global__ __launch_bounds__(256) void pack_staged_kernel(const void *__restrict__ src, uint4 *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
-                                                          int slow, uint32_t npf, uint32_t nbm, uint64_t n_pieces) {
-    constexpr int VPP = U8 ? 16 : 8;
-    const int F = (slow + 1) % 3, M = (slow + 2) % 3, S = slow;
-    const int n[3] = {(int)nx, (int)ny, (int)nz};
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_pieces; id += stride) {
-        const uint64_t brick = id >> 6;
-        const uint32_t w = (uint32_t)(id & 63u);
-        const uint32_t pf = (uint32_t)(brick % npf);
-        const uint64_t rest = brick / npf;
-        const uint32_t bm = (uint32_t)(rest % nbm), bs = (uint32_t)(rest / nbm);
-        int c[3];
-        c[M] = clampi((int)(bm * 8 + (w & 7u)) - kStagePad, 0, n[M] - 1);
-        c[S] = clampi((int)(bs * 8 + (w >> 3)) - kStagePad, 0, n[S] - 1);
-        union { uint4 u; uint8_t b[16]; uint16_t h[8]; } o;
-#pragma unroll
-        for (int e = 0; e < VPP; e++) {
-            c[F] = clampi((int)(pf * VPP) + e - kStagePad, 0, n[F] - 1);
-            const size_t idx = (size_t)c[0] + (size_t)nx * ((size_t)c[1] + (size_t)ny * (size_t)c[2]);
-            if (U8) o.b[e] = reinterpret_cast<const uint8_t *>(src)[idx];
-            else o.h[e] = reinterpret_cast<const uint16_t *>(src)[idx];
-        }
-        dst[id] = o.u;
-    }
 }
 
 // The 8 taps of a sample from the LDS window: pair k (two consecutive elements along the FAST axis) at byte
@@ -667,7 +624,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int c0 = __popcll(__ballot(hit && mj == 0)), c1 = __popcll(__ballot(hit && mj == 1)), c2 = __popcll(__ballot(hit && mj == 2));
     Census cs;
     if (c0 + c1 + c2 != 0) {  // wave-uniform
-        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
+        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
         if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane);
@@ -683,7 +640,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     store_out<OUT>(L, pm, Cr, Cg, Cb);
     if (COUNT) {
-        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 2u) ? cs.n_fb : ((L.debug_flags & 1u) ? cs.n_look : cs.n_iter);
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.flags & LF_STEPS_ARE_FALLBACKS) ? cs.n_fb : ((L.flags & LF_STEPS_ARE_TRIPS) ? cs.n_look : cs.n_iter);
         if (L.counters) {
             atomicAdd(&L.counters[0], (unsigned long long)cs.n_iter);
             atomicAdd(&L.counters[1], (unsigned long long)cs.n_samp);
@@ -778,7 +735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int c0 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 0]), c1 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 1]), c2 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 2]);
     Census cs;
     if (c0 + c1 + c2 != 0) {  // group-uniform
-        if (L.debug_flags & 16u) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
+        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
         // (the S axis of copy k is axis k: the direction of travel is counted on that axis)
@@ -802,7 +759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     store_out<OUT>(L, pm, Cr, Cg, Cb);
     if (COUNT) {
-        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.debug_flags & 2u) ? cs.n_fb : ((L.debug_flags & 1u) ? cs.n_look : cs.n_iter);
+        if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = (L.flags & LF_STEPS_ARE_FALLBACKS) ? cs.n_fb : ((L.flags & LF_STEPS_ARE_TRIPS) ? cs.n_look : cs.n_iter);
         if (L.counters) {
             atomicAdd(&L.counters[0], (unsigned long long)cs.n_iter);
             atomicAdd(&L.counters[1], (unsigned long long)cs.n_samp);

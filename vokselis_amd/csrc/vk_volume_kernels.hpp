@@ -1,0 +1,348 @@
+// vk_volume_kernels.hpp -- VolumeTexture::new (src/context/volume_texture.rs:32-59) on the device: re-layout of the dense
+// x-fastest volume into cells / bricks / records, skip maps, index tables, and the deterministic generators (fog, bonsai
+// stand-in, shaders/xor.wgsl cs_main).  Included by vk_volume.hip only.
+#pragma once
+
+#include "vk_common.hpp"
+#include "vk_xor.hpp"
+
+namespace vk {
+
+// Built once per volume (two copies back to back: cell units, then byte offsets) ...
+__global__ __launch_bounds__(256) void build_cell_luts_kernel(uint32_t *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx,
+                                                               uint32_t nby, uint32_t byte_shift) {
+    const uint32_t n0 = nx + 3u, n1 = ny + 3u, n2 = nz + 3u, total = n0 + n1 + n2, padded = cell_lut_entries(nx, ny, nz);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < padded; e += gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        if (e < total) {
+            uint32_t j = e, n = n0, brick_mul = 64u, cell_mul = 1u;
+            if (e >= n0 + n1) { j = e - n0 - n1; n = n2; brick_mul = 64u * nbx * nby; cell_mul = 16u; }
+            else if (e >= n0) { j = e - n0; n = n1; brick_mul = 64u * nbx; cell_mul = 4u; }
+            const uint32_t c = min(max(j, 1u), n - 2u) - 1u;  // cell coordinate i + 1 in [0, n_vox]
+            v = brick_mul * ((c + 3u) >> 2) + cell_mul * ((c + 3u) & 3u);
+        }
+        out[e] = v;
+        out[padded + e] = v << byte_shift;
+    }
+}
+
+__global__ __launch_bounds__(256) void build_pair_luts_kernel(uint32_t *__restrict__ out, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby) {
+    const uint32_t n0 = nx + 2u * kPairPad, n1 = ny + 2u * kPairPad, n2 = nz + 2u * kPairPad, total = n0 + n1 + n2, padded = pair_lut_entries(nx, ny, nz);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < padded; e += gridDim.x * blockDim.x) {
+        uint32_t v = kPairOob;
+        if (e < total) {
+            uint32_t j = e, n = nx, brick_mul = 64u, cell_mul = 1u;
+            if (e >= n0 + n1) { j = e - n0 - n1; n = nz; brick_mul = 64u * nbx * nby; cell_mul = 16u; }
+            else if (e >= n0) { j = e - n0; n = ny; brick_mul = 64u * nbx; cell_mul = 4u; }
+            if (j >= kPairPad && j < n + kPairPad) { const uint32_t i = j - kPairPad; v = (brick_mul * (i >> 2) + cell_mul * (i & 3u)) << 4; }
+        }
+        out[e] = v;
+    }
+}
+
+// dense x-fastest (density, normals) -> bricked 16-byte records
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2 *__restrict__ den, const uint2 *__restrict__ nrm, uint4 *__restrict__ dst,
+                                                         uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_rec) {
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_rec; id += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t brick = id >> 6;
+        const uint32_t w = (uint32_t)(id & 63u);
+        const uint32_t bx = (uint32_t)(brick % nbx);
+        const uint64_t rest = brick / nbx;
+        const uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        const uint32_t x = bx * 4 + (w & 3u), y = by * 4 + ((w >> 2) & 3u), z = bz * 4 + (w >> 4);
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (x < nx && y < ny && z < nz) {
+            const size_t src = (size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)z);
+            const uint2 d = den[src], n = nrm[src];
+            r = make_uint4(d.x, d.y, n.x, n.y);
+        }
+        dst[id] = r;
+    }
+}
+
+// ---- volume re-layout ------------------------------------------------------------------------
+// One thread per cell, cells enumerated in storage order (coalesced 8/16-byte stores).  Physical
+// brick B = (i >> 2) + 1 and in-brick w = i & 3 per axis, i = low-corner voxel index in [-1, n-1].
+template <int VOL>
+__global__ __launch_bounds__(256) void pack_cells_kernel(const void *__restrict__ src, void *__restrict__ dst,
+                                                          uint8_t *__restrict__ occ, uint32_t nx, uint32_t ny,
+                                                          uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_cells,
+                                                          unsigned long long *__restrict__ n_empty) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_cells) return;
+    uint64_t brick = id >> 6;
+    uint32_t w = (uint32_t)(id & 63u);
+    uint32_t bx = (uint32_t)(brick % nbx);
+    uint64_t rest = brick / nbx;
+    uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+    int ix = ((int)bx - 1) * 4 + (int)(w & 3u), iy = ((int)by - 1) * 4 + (int)((w >> 2) & 3u), iz = ((int)bz - 1) * 4 + (int)(w >> 4);
+    int mx = (int)nx - 1, my = (int)ny - 1, mz = (int)nz - 1;
+    int xs[2] = {clampi(ix, 0, mx), clampi(ix + 1, 0, mx)};
+    int ys[2] = {clampi(iy, 0, my), clampi(iy + 1, 0, my)};
+    int zs[2] = {clampi(iz, 0, mz), clampi(iz + 1, 0, mz)};
+    uint32_t t[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        size_t idx = (size_t)xs[b & 1] + (size_t)nx * ((size_t)ys[(b >> 1) & 1] + (size_t)ny * (size_t)zs[b >> 2]);
+        t[b] = (VOL == VOL_PF16) ? (uint32_t)reinterpret_cast<const uint16_t *>(src)[idx]
+                                 : (uint32_t)reinterpret_cast<const uint8_t *>(src)[idx];
+    }
+    // occ = 0 if any tap is above the transfer function's zero threshold (u8 > 25: 25/255 < 0.1 <=
+    // 26/255; f16 > 0.1f or NaN), else 255 ("no contributing cell seen yet")
+    bool nonempty = false;
+#pragma unroll
+    for (int b = 0; b < 8; b++) nonempty |= (VOL == VOL_PF16) ? !(h2f(t[b]) <= 0.1f) : (t[b] > 25u);
+    occ[id] = nonempty ? 0 : 255;
+    {   // census of exactly-transparent cells (one atomic per wave): decides whether skipping can pay
+        const unsigned long long m = __ballot(!nonempty);
+        if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_empty, (unsigned long long)__popcll(m));
+    }
+    if (VOL == VOL_P8) {
+        uint32_t lo = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+        uint32_t hi = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
+        reinterpret_cast<uint2 *>(dst)[id] = make_uint2(lo, hi);
+    } else if (VOL == VOL_P16) {
+        union { uint4 u; _Float16 h[8]; } c;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c.h[2 * k] = (_Float16)(float)t[2 * k];                                  // tap (dx = 0)
+            c.h[2 * k + 1] = (_Float16)((float)t[2 * k + 1] - (float)t[2 * k]);      // delta, |.| <= 255: exact
+        }
+        reinterpret_cast<uint4 *>(dst)[id] = c.u;
+    } else {
+        reinterpret_cast<uint4 *>(dst)[id] = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+    }
+}
+
+// Dense voxels -> 9^3 bricks: one thread per stored voxel, brick b holds voxels [8b-1, 8b+7] per axis
+// (clamped to the volume: clamp-to-edge is baked in).
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_bricks9_kernel(const void *__restrict__ src, void *__restrict__ dst, uint32_t nx,
+                                                           uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_elems) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_elems; id += stride) {  // may exceed 2^32
+        uint64_t brick = id / 729u;
+        uint32_t l = (uint32_t)(id - brick * 729u);
+        uint32_t lz = l / 81u, ly = (l - lz * 81u) / 9u, lx = l - lz * 81u - ly * 9u;
+        uint32_t bx = (uint32_t)(brick % nbx);
+        uint64_t rest = brick / nbx;
+        uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        int x = clampi((int)(bx * 8 + lx) - 1, 0, (int)nx - 1), y = clampi((int)(by * 8 + ly) - 1, 0, (int)ny - 1);
+        int z = clampi((int)(bz * 8 + lz) - 1, 0, (int)nz - 1);
+        size_t idx = (size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)z);
+        if (F16) reinterpret_cast<uint16_t *>(dst)[id] = reinterpret_cast<const uint16_t *>(src)[idx];
+        else reinterpret_cast<uint8_t *>(dst)[id] = reinterpret_cast<const uint8_t *>(src)[idx];
+    }
+}
+
+// Dense voxels -> quad elements in 9x8x8 bricks.  Padded coordinate c = i + 1 (i = low-corner voxel of a
+// footprint, i in [-1, n-1]) maps to voxel clamp(c - 1); brick (cx>>3, cy>>3, cz>>3), local (cx&7 .. with the
+// x apron lx = 8 repeating the next brick's lx = 0).  One thread per element.
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_quads_kernel(const void *__restrict__ src, void *__restrict__ dst, uint32_t nx, uint32_t ny,
+                                                         uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_elems) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_elems; id += stride) {
+        const uint64_t brick = id / 576u;
+        const uint32_t l = (uint32_t)(id - brick * 576u);
+        const uint32_t lz = l / 72u, ly = (l - lz * 72u) / 9u, lx = l - lz * 72u - ly * 9u;
+        const uint32_t bx = (uint32_t)(brick % nbx);
+        const uint64_t rest = brick / nbx;
+        const uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+        const int cx = (int)(bx * 8 + lx), cy = (int)(by * 8 + ly), cz = (int)(bz * 8 + lz);
+        const int x = clampi(cx - 1, 0, (int)nx - 1);
+        const int y0 = clampi(cy - 1, 0, (int)ny - 1), y1 = clampi(cy, 0, (int)ny - 1);
+        const int z0 = clampi(cz - 1, 0, (int)nz - 1), z1 = clampi(cz, 0, (int)nz - 1);
+        const size_t sy_ = nx, sz_ = (size_t)nx * ny;
+        const size_t i00 = x + y0 * sy_ + z0 * sz_, i10 = x + y1 * sy_ + z0 * sz_, i01 = x + y0 * sy_ + z1 * sz_, i11 = x + y1 * sy_ + z1 * sz_;
+        if (F16) {
+            const uint16_t *v = reinterpret_cast<const uint16_t *>(src);
+            reinterpret_cast<uint2 *>(dst)[id] = make_uint2((uint32_t)v[i00] | ((uint32_t)v[i10] << 16), (uint32_t)v[i01] | ((uint32_t)v[i11] << 16));
+        } else {
+            const uint8_t *v = reinterpret_cast<const uint8_t *>(src);
+            reinterpret_cast<uint32_t *>(dst)[id] = (uint32_t)v[i00] | ((uint32_t)v[i10] << 8) | ((uint32_t)v[i01] << 16) | ((uint32_t)v[i11] << 24);
+        }
+    }
+}
+
+// One separable pass of the Chebyshev (L-infinity) distance transform over the cells:
+// out(c) = min_j max(in(c + j*axis), |j|), |j| <= kDistRadius, j restricted to j >= 0 (dir > 0),
+// j <= 0 (dir < 0) or unrestricted (dir == 0).  Outside the grid counts as empty.
+// Cells are addressed in their bricked storage order.
+__device__ __forceinline__ uint64_t cell_index(uint32_t x, uint32_t y, uint32_t z, uint32_t nbx, uint32_t nby) {
+    uint64_t brick = ((uint64_t)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
+    return brick * 64 + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
+}
+
+__global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                        uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int dir, int last) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n = (uint64_t)nbx * nby * nbz * 64;
+    if (id >= n) return;
+    uint64_t brick = id >> 6;
+    uint32_t w = (uint32_t)(id & 63u);
+    uint32_t bx = (uint32_t)(brick % nbx);
+    uint64_t rest = brick / nbx;
+    uint32_t by = (uint32_t)(rest % nby), bz = (uint32_t)(rest / nby);
+    uint32_t c[3] = {bx * 4 + (w & 3u), by * 4 + ((w >> 2) & 3u), bz * 4 + (w >> 4)};
+    const int dim = (int)(axis == 0 ? nbx : (axis == 1 ? nby : nbz)) * 4;
+    const int c0 = (int)c[axis];
+    int best = in[id];
+    const int jlo = dir > 0 ? 0 : max(-kDistRadius, -c0), jhi = dir < 0 ? 0 : min(kDistRadius, dim - 1 - c0);
+    for (int j = jlo; j <= jhi; j++) {
+        const int aj = j < 0 ? -j : j;
+        if (aj >= best) continue;  // cannot improve
+        uint32_t q[3] = {c[0], c[1], c[2]};
+        q[axis] = (uint32_t)(c0 + j);
+        const int v = in[cell_index(q[0], q[1], q[2], nbx, nby)];
+        best = min(best, max(v, aj));
+    }
+    if (last) best = min(best, kDistRadius + 1);
+    out[id] = (uint8_t)best;
+}
+
+// ---- misc ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z, uint32_t seed) {
+    return lowbias32(seed ^ (x * 0x9E3779B1U + y * 0x85EBCA77U + z * 0xC2B2AE3DU));
+}
+
+// Deterministic synthetic volumes, integer arithmetic only (bit-identical to the oracle's
+// vo_volume_fog_u8 / vo_volume_fog_f16 / vo_volume_standin_u8 and to vokselis_amd/volumes.py).
+__device__ __forceinline__ uint32_t vnoise(uint32_t X, uint32_t Y, uint32_t Z, uint32_t sh, uint32_t seed) {
+    const uint32_t m = (1u << sh) - 1, S = 1u << sh;
+    const uint32_t cx = X >> sh, cy = Y >> sh, cz = Z >> sh;
+    const uint32_t fx = X & m, fy = Y & m, fz = Z & m;
+    uint64_t acc = 0;
+#pragma unroll
+    for (uint32_t dz = 0; dz < 2; dz++)
+#pragma unroll
+        for (uint32_t dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (uint32_t dx = 0; dx < 2; dx++) {
+                uint64_t w = (uint64_t)(dx ? fx : S - fx) * (dy ? fy : S - fy) * (dz ? fz : S - fz);
+                acc += w * (hash3(cx + dx, cy + dy, cz + dz, seed) >> 24);
+            }
+    return (uint32_t)(acc >> (3 * sh));
+}
+
+// "bonsai stand-in": dense pot (>= 232), mid-density bent trunk, smooth noise-thresholded canopy,
+// air = white noise 0..20 (exactly transparent) with 0.2 % speckle 26..41.  SURVEY 8(d) C1.
+__device__ __forceinline__ uint32_t standin_voxel(uint32_t x, uint32_t y, uint32_t z, uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed) {
+    const int32_t X = (int32_t)(((2 * (uint64_t)x + 1) * 2048) / nx);
+    const int32_t Y = (int32_t)(((2 * (uint64_t)y + 1) * 2048) / ny);
+    const int32_t Z = (int32_t)(((2 * (uint64_t)z + 1) * 2048) / nz);
+    const uint32_t n_lo = vnoise((uint32_t)X, (uint32_t)Y, (uint32_t)Z, 9, seed ^ 0x1111u);
+    const uint32_t n_hi = vnoise((uint32_t)X, (uint32_t)Y, (uint32_t)Z, 7, seed ^ 0x2222u);
+    {
+        int64_t dx = X - 2048, dy = Y - 600, dz = Z - 2048;
+        if (dx * dx + 7 * dy * dy + dz * dz < 1400 * 1400) return 232 + (n_hi >> 4);
+    }
+    if (Y >= 900 && Y < 2600) {
+        int32_t h = Y - 900;
+        int64_t cx = 2048 + ((int64_t)h * h) / 8000, cz = 2048 - h / 6, rr = 230 - h / 12;
+        int64_t dx = X - cx, dz = Z - cz;
+        if (dx * dx + dz * dz < rr * rr) return 110 + (n_hi >> 2);
+    }
+    {
+        int64_t dx = X - 2150, dy = Y - 2850, dz = Z - 1950;
+        int64_t q = (dx * dx * 256) / (1750 * 1750) + (dy * dy * 256) / (1050 * 1050) + (dz * dz * 256) / (1750 * 1750);
+        if (q < 256) {
+            int32_t f = (int32_t)((2 * n_lo + n_hi) / 3);
+            int32_t d = f - (int32_t)(q / 3) - 52;
+            if (d > 0) { int32_t v = 28 + 2 * d; return (uint32_t)(v > 225 ? 225 : v); }
+        }
+    }
+    const uint32_t h = hash3(x, y, z, seed ^ 0x3333u);
+    if ((h & 0x1ffu) == 0) return 26 + ((h >> 9) & 15);
+    return (h >> 16) % 21;
+}
+
+// kind 0: fog u8 in [lo, lo+span); 1: fog f16 bit patterns 0x2D1F + h % 656; 2: bonsai stand-in u8.
+// core: the fog with a dense ball at the centre (SURVEY 8d, C4 / C5 "dense-core variant"): a voxel is in the core iff
+// (2x+1-nx)^2 + (2y+1-ny)^2 + (2z+1-nz)^2 < (min(nx,ny,nz)/2)^2 (radius: a quarter of the smallest dimension); there
+// u8 = 232 + h % 24 (alpha per step >= 0.8: a ray that enters leaves the loop within two steps), f16 = 0x3B9A + h % 64
+// (0.95 .. 0.98).  Integer arithmetic only.
+__host__ __device__ __forceinline__ bool in_dense_core(uint32_t x, uint32_t y, uint32_t z, uint32_t nx, uint32_t ny, uint32_t nz) {
+    const int64_t dx = 2 * (int64_t)x + 1 - (int64_t)nx, dy = 2 * (int64_t)y + 1 - (int64_t)ny, dz = 2 * (int64_t)z + 1 - (int64_t)nz;
+    const int64_t r = (int64_t)(nx < ny ? (nx < nz ? nx : nz) : (ny < nz ? ny : nz)) / 2;
+    return dx * dx + dy * dy + dz * dz < r * r;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void generate_kernel(void *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
+                                                       uint32_t seed, uint32_t lo, uint32_t span, uint32_t core) {
+    const uint64_t n = (uint64_t)nx * ny * nz, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += stride) {  // grid-stride: n may exceed 2^32
+        uint32_t x = (uint32_t)(id % nx);
+        uint64_t rest = id / nx;
+        uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
+        if (KIND == 2) {
+            reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)standin_voxel(x, y, z, nx, ny, nz, seed);
+        } else {
+            uint32_t h = hash3(x, y, z, seed) >> 8;
+            const bool dense = core && in_dense_core(x, y, z, nx, ny, nz);
+            if (KIND == 1) reinterpret_cast<uint16_t *>(dst)[id] = (uint16_t)(dense ? 0x3B9Au + h % 64u : 0x2D1Fu + h % 656u);
+            else reinterpret_cast<uint8_t *>(dst)[id] = (uint8_t)(dense ? 232u + h % 24u : lo + h % span);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void xor_generate_kernel(uint2 *__restrict__ density, uint2 *__restrict__ normals,
+                                                           uint32_t nx, uint32_t ny, uint32_t nz, float time) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)nx * ny * nz) return;
+    const uint32_t x = (uint32_t)(id % nx);
+    const uint64_t rest = id / nx;
+    const uint32_t y = (uint32_t)(rest % ny), z = (uint32_t)(rest / ny);
+    const float d0 = (float)nx, d1 = (float)ny, d2 = (float)nz;
+    const float c0 = ((float)x - d0 / 2.0f) / d0, c1 = ((float)y - d1 / 2.0f) / d1, c2 = ((float)z - d2 / 2.0f) / d2;
+    const float off1 = sin_spec(time * 1.0f) * 0.1f;
+    float val, alpha, v1, a0, a1, a2;
+    xor_noise_volume(c0, c1, c2, off1, val, alpha);
+    xor_noise_volume(c0 - 0.0001f, c1, c2, off1, v1, a0);
+    xor_noise_volume(c0, c1 - 0.0001f, c2, off1, v1, a1);
+    xor_noise_volume(c0, c1, c2 - 0.0001f, off1, v1, a2);
+    const float g0 = alpha - a0, g1 = alpha - a1, g2 = alpha - a2;
+    const float nl = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+    const float n0 = g0 / nl, n1 = g1 / nl, n2 = g2 / nl;  // normalize(0) = NaN, as on any GPU
+    const float ln = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
+    union { _Float16 h[4]; uint2 u; } dv, nv;
+    dv.h[0] = (_Float16)(val / 2.0f); dv.h[1] = dv.h[0]; dv.h[2] = dv.h[0]; dv.h[3] = (_Float16)alpha;
+    nv.h[0] = (_Float16)n0; nv.h[1] = (_Float16)n1; nv.h[2] = (_Float16)n2; nv.h[3] = (_Float16)ln;
+    density[id] = dv.u;
+    normals[id] = nv.u;
+}
+
+// Dense voxels -> one staged copy.  One thread per 16-byte piece, pieces enumerated in storage order.
+template <bool U8>
+__global__ __launch_bounds__(256) void pack_staged_kernel(const void *__restrict__ src, uint4 *__restrict__ dst, uint32_t nx, uint32_t ny, uint32_t nz,
+                                                          int slow, uint32_t npf, uint32_t nbm, uint64_t n_pieces) {
+    constexpr int VPP = U8 ? 16 : 8;
+    const int F = (slow + 1) % 3, M = (slow + 2) % 3, S = slow;
+    const int n[3] = {(int)nx, (int)ny, (int)nz};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_pieces; id += stride) {
+        const uint64_t brick = id >> 6;
+        const uint32_t w = (uint32_t)(id & 63u);
+        const uint32_t pf = (uint32_t)(brick % npf);
+        const uint64_t rest = brick / npf;
+        const uint32_t bm = (uint32_t)(rest % nbm), bs = (uint32_t)(rest / nbm);
+        int c[3];
+        c[M] = clampi((int)(bm * 8 + (w & 7u)) - kStagePad, 0, n[M] - 1);
+        c[S] = clampi((int)(bs * 8 + (w >> 3)) - kStagePad, 0, n[S] - 1);
+        union { uint4 u; uint8_t b[16]; uint16_t h[8]; } o;
+#pragma unroll
+        for (int e = 0; e < VPP; e++) {
+            c[F] = clampi((int)(pf * VPP) + e - kStagePad, 0, n[F] - 1);
+            const size_t idx = (size_t)c[0] + (size_t)nx * ((size_t)c[1] + (size_t)ny * (size_t)c[2]);
+            if (U8) o.b[e] = reinterpret_cast<const uint8_t *>(src)[idx];
+            else o.h[e] = reinterpret_cast<const uint16_t *>(src)[idx];
+        }
+        dst[id] = o.u;
+    }
+}
+
+}  // namespace vk

@@ -30,7 +30,7 @@ def tiles_xy(width: int, height: int, tile_size: int):
 
 def deal_pos(rank: int, slot: int, world: int, root_skip: int = 0) -> int:
     """Position of the tile order that (rank, slot) marches.  Rounds give one position to every rank; with
-    root_skip = k >= 2 rank 0 sits out every k-th round (vk_partition_root_skip; deal_pos of vk_kernels.hpp)."""
+    root_skip = k >= 2 rank 0 sits out every k-th round (vk_partition_root_skip; deal_pos of vk_common.hpp)."""
     k = root_skip
     if k < 2:
         return rank + slot * world
