@@ -77,8 +77,13 @@ enum vk_render_flags {
                                  dense kernel below 45 % of exactly transparent cells, adaptive probing from 45 %, probing on every trip from 55 %) */
     VK_RENDER_DEBUG_TRIPS = 16, /* with COUNT: vk_readback_steps returns march-loop trips (lookups) per pixel */
     VK_RENDER_DEBUG_FALLBACK = 32, /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
-    VK_RENDER_PROBE_ALWAYS = 64 /* skip kernels: look the distance map up on every trip (no adaptive dense stretches): S_sampled is then
+    VK_RENDER_PROBE_ALWAYS = 64, /* skip kernels: look the distance map up on every trip (no adaptive dense stretches): S_sampled is then
                                    exactly the number of steps that can contribute; the frame is the same either way */
+    VK_RENDER_FAST_WALK = 128 /* TOLERANCE MODE of the skip kernels: a run of exactly transparent steps advances the ray in closed form
+                                 (one fma per accumulator) instead of by the reference loop's own sequence of rounded additions
+                                 (raycast_naive.wgsl:101,118).  Frames stay within the contract's 1e-4 per channel of the default,
+                                 bit-exact mode (measured ~1e-5) but are not bit-identical to it, and a ray's iteration count may
+                                 differ by one at its end.  Ignored by kernels that do not skip. */
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */

@@ -17,7 +17,7 @@ OUT_RGBA32F, OUT_RGBA16F = 0, 1
 LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, LAYOUT_QUADS, LAYOUT_STAGED = 0, 1, 2, 3, 4, 5, 6
 RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
-RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS = 32, 64
+RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS, RENDER_FAST_WALK = 32, 64, 128
 WIRE_RGBA, WIRE_RGB = 0, 1
 GEN_FOG, GEN_BONSAI_STANDIN, GEN_FOG_DENSE_CORE = 0, 1, 2
 

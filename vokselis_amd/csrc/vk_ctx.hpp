@@ -164,7 +164,7 @@ int dispatch_march(vk_ctx *ctx, int mode, const vk::LaunchDesc &L_in, uint32_t f
 uint32_t launch_flags(const vk_ctx *ctx, uint32_t render_flags, bool batch);
 
 // the kernel-instantiating TUs: each launches on ctx->stream and returns; the caller checks hipGetLastError
-void launch_cells(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool skip, bool safe);
+void launch_cells(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool skip, bool safe, int walk /* vk_march.hpp: WalkKind */);
 void launch_staged(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, const float *cam);
 void launch_compute(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool records);
 void launch_procedural(vk_ctx *ctx, const vk::LaunchDesc &L, uint32_t grid, bool count, float time);

@@ -85,7 +85,21 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 // instructions of the closed form -- the loop is VALU-issue bound.  Every table entry is a valid
 // non-negative partial index and LDS reads outside the allocation return 0, so any combination stays
 // inside the cell array: no clamp.
-template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false>
+//
+// WALK: how a run of exactly transparent steps advances the reference's accumulators (t += dt, p += s: raycast_naive.wgsl:101,118).
+//   WALK_LOOP  the additions themselves, four per loop iteration, capped per trip: bit-exact, the default.
+//   WALK_FMA   VK_RENDER_FAST_WALK, tolerance mode: one real addition, then m more steps as ONE fma with the rounded increment of
+//              that addition, v_1 + m (v_1 - v_0).  Inside a binade every rounded addition of the same addend moves an accumulator
+//              by the same amount, so this IS the reference's value unless the accumulator crosses a power of two during the walk;
+//              there it parts from the reference by at most (steps after the crossing) x half an ulp.  Positions agree to ~2e-4
+//              cell, frames to 1e-4 at the 99.99th percentile of C2's pixels; 0.3 % of the rays take one iteration more or fewer
+//              (the last `t < t1`), and a few hundred pixels per frame flip their alpha >= 0.95 early-out
+//              (profiles/r04_walk_modes.txt).  No cap: a walk of any length costs the same dozen instructions.
+//   (Cutting the closed form at every binade boundary makes it exact again -- and 15 - 37 % slower than the loop: every crossing
+//   costs the lane another probing trip.  docs/history/experiments/skip_walk_binade_cut_closed_form.patch)
+enum WalkKind : int { WALK_LOOP = 0, WALK_FMA = 2 };
+
+template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false, int WALK = WALK_LOOP>
 __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs,
                                       const uint32_t *lut = nullptr, const float walk_cap = __builtin_inff(), const float walk_cap_all = __builtin_inff()) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
@@ -125,6 +139,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, SAFE ? 0u : (uint32_t)V.max_off + (1u << V.sh_x));
     const float t1q = __builtin_canonicalizef(t1);  // known-quiet copy: keeps a per-trip canonicalise out of the skip branch
+    const float idt = (SKIP && WALK == WALK_FMA) ? __builtin_amdgcn_rcpf(dt) : 0.0f;  // (1 ulp: it only places the last skipped step against t1)
 
     // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
     // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
@@ -182,6 +197,17 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 // iteration passed the reference's `t < t1` test on the very same t; and t_j < tstop
                 // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
                 float rmin = fminf(fminf(rx, ry), rz);
+                if constexpr (WALK == WALK_FMA) {
+                    // Samples j = 0 .. m are skipped: j < r keeps them inside the empty range, j < (t1 - t) / dt inside the ray (the
+                    // current sample's cell is empty: m >= 0).  The first step as the reference takes it, the rest by its increment.
+                    const float m = fmaxf(__builtin_ceilf(fminf(rmin, (t1q - t) * idt)) - 1.0f, 0.0f);
+                    const float t_1 = t + dt, x_1 = px + sx, y_1 = py + sy, z_1 = pz + sz;
+                    const float dt_q = t_1 - t, dx_q = x_1 - px, dy_q = y_1 - py, dz_q = z_1 - pz;
+                    t = fmaf(m, dt_q, t_1);
+                    px = fmaf(m, dx_q, x_1); py = fmaf(m, dy_q, y_1); pz = fmaf(m, dz_q, z_1);
+                    if (COUNT) { n_iter += 1u + (uint32_t)m; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
+                    continue;
+                }
                 asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
                 float tstop = fmaf(rmin, dt, t);
                 asm("v_min_f32 %0, %1, %2" : "=v"(tstop) : "v"(tstop), "v"(t1q));    // (t1 is finite: no canonicalise per trip)
@@ -538,9 +564,10 @@ __device__ __forceinline__ void clear_inactive_strip(const LaunchDesc &L, uint32
     }
 }
 
-template <int VOL, bool SKIP, bool SAFE, int OUT, bool COUNT>
+template <int VOL, bool SKIP, bool SAFE, int WALK, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
+    static_assert(SKIP || WALK == WALK_LOOP, "the closed-form walks are variants of the skip kernels");
     if (blockIdx.x >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x - L.grid_march, threadIdx.x); return; }  // wave-uniform
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                 uint32_t stretch = stretch0;
                 for (;;) {
                     cs.skips = 0;
-                    bool alive = march<VOL, true, SAFE, COUNT, true>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
+                    bool alive = march<VOL, true, SAFE, COUNT, true, WALK>(V, r, 16u, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
                     const unsigned long long live = __ballot(alive);
                     if (live == 0ull) break;
                     if (__popcll(__ballot(alive && cs.skips != 0u)) * 8 >= __popcll(live)) { stretch = stretch0; continue; }
@@ -629,7 +656,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     stretch = min(stretch * 2u, 512u);
                 }
             } else {
-                march<VOL, SKIP, SAFE, COUNT>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
+                march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
             }
         }
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);

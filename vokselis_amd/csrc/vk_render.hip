@@ -106,7 +106,7 @@ int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags
             if (V.max_off + 16 < (1ll << 32) && cell_lut_bytes(ctx->nx, ctx->ny, ctx->nz) <= 16384u && 64.0f * ulp < 0.25f / nmax && !(flags & VK_RENDER_SAFE)) safe = false;
         }
         if (ctx->vol_kind == VOL_S8U8 || ctx->vol_kind == VOL_S8F16) launch_staged(ctx, L, V, grid, count, reach_cam);
-        else launch_cells(ctx, L, V, grid, count, skip, safe);
+        else launch_cells(ctx, L, V, grid, count, skip, safe, (flags & VK_RENDER_FAST_WALK) ? 2 : 0);  // (vk_march.hpp: WalkKind)
     }
     HIP_TRY(ctx, hipGetLastError());
     return VK_OK;
