@@ -462,6 +462,8 @@ def main():
 
         elapsed, evs, run_order_ms = measure()
         root_skip_fixed = btr.root_skip if use_dist else 0
+        wire_info = {"format": "rgb" if btr.ch == 3 else "rgba", "bytes_per_pixel": ctx.wire_pixel_bytes, "slot_capacity": btr.cap,
+                     "tile_bytes": TILE * TILE * ctx.wire_pixel_bytes} if use_dist else None
         # the same window with the config's ONE camera in every frame (what round 2 reported as the headline)
         still_elapsed, still_evs = None, []
         if not args.headline_only:
@@ -482,14 +484,26 @@ def main():
         # bytes over every link of the node.  Reported beside `value`, which stays the gather to rank 0.
         rot_elapsed, rot_error = None, None
         if use_dist and world > 1 and not args.no_rotate:
-            try:  # (a failure here must not cost the line its headline: it is reported in rotating_root instead)
+            # Only the SET-UP may fail softly, and only for everybody at once: the ranks agree on its outcome (as for the first renderer
+            # above) and drop `rotating_root` together.  The timed window itself is full of collectives; an exception inside it on one
+            # rank would leave the others parked in a barrier, so it is not caught: it ends the job through the launcher.
+            why = None
+            try:
                 btr.close()
                 btr = None
                 btr = BatchTileRenderer(ctx, pipe, tile_size=TILE, batch=batch, root="rotate", transport=transport, via_host=rehearsal)
+            except Exception as e:  # noqa: BLE001
+                why = repr(e)
+            okt = torch.tensor([0 if why else 1], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()):
                 timed_region(batch * min(world, 4), False)
                 rot_elapsed, _, _ = measure()
-            except Exception as e:  # noqa: BLE001
-                rot_error = repr(e)
+            else:
+                rot_error = why or "set-up of the rotating-root renderer failed on another rank"
+                if btr is not None:
+                    btr.close()
+                    btr = None
         n_launch_frames = batch  # frames one launch spans
         launch_ms = None
         if evs:
@@ -613,8 +627,7 @@ def main():
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
                 out["config"]["root_skip"] = root_skip_fixed
                 # what a peer puts on its link to the root per frame: its active slots, colour only (alpha is 1 in every pixel)
-                out["config"]["wire"] = {"format": "rgb" if btr.ch == 3 else "rgba", "bytes_per_pixel": ctx.wire_pixel_bytes,
-                                         "slot_capacity": btr.cap, "tile_bytes": TILE * TILE * ctx.wire_pixel_bytes}
+                out["config"]["wire"] = wire_info
 
         # One frame per launch -- the reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) -- on the
         # config's camera: duration of a single-frame launch and its spread, back to back on a busy GPU.

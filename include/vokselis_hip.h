@@ -235,6 +235,10 @@ int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, u
  * (a) one process per GPU (MPI / torchrun style): rank 0 makes an id, the host ships its 128 bytes to the peers,
  *     every rank joins; then per batch vk_render_batch(compact) -> vk_gather_tiles -> (root) vk_untile_batch. */
 #define VK_COMM_ID_BYTES 128
+/* Can this process load and bind RCCL (librccl.so.1, or what VK_RCCL_LIB names)?  VK_OK, or VK_ERR_UNSUPPORTED with the reason in
+ * vk_last_error(NULL).  No side effect beyond loading the library: the probe every rank can make before any of them enters the
+ * blocking vk_comm_init_rank.  (vk_comm_unique_id opens a bootstrap listener for the ranks to come: call it on ONE rank.) */
+int vk_comm_available(void);
 int vk_comm_unique_id(void *id128);
 int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks);
 int vk_comm_destroy(vk_ctx *ctx);

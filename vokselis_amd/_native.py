@@ -56,6 +56,7 @@ SYMBOLS = {
     "vk_render_batch": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _u32, _u32, _f32, _u32, _vp, C.c_int, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "vk_untile_batch": (C.c_int, [_vp, _u32, _vp, _u32, _vp]),
     "vk_untile_batch_over": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _u32]),
+    "vk_comm_available": (C.c_int, []),
     "vk_comm_unique_id": (C.c_int, [_vp]),
     "vk_comm_init_rank": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "vk_comm_destroy": (C.c_int, [_vp]),

@@ -43,13 +43,23 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     vk_ctx::BatchSlot &B = ctx->batch[ctx->batch_seq % 4u];
     if (B.ev) HIP_TRY(ctx, hipEventSynchronize(B.ev));  // the launches of four batches ago have long finished
     else HIP_TRY(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+    if (!ctx->batch_retired.empty()) {
+        // outgrown table blocks: free them once nothing in flight can still read them, i.e. when every slot's last launch has completed
+        bool idle = true;
+        for (auto &b : ctx->batch) if (b.ev && hipEventQuery(b.ev) != hipSuccess) idle = false;
+        (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error to find after the launch below)
+        if (idle) { for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); } ctx->batch_retired.clear(); }
+    }
     B.id = 0;  // claimed: whatever fails below, the slot no longer answers to its old id
     if (B.cap < bytes) {
         // sized for 256 frames from the start and doubled from there; the outgrown blocks are retired, not freed (hipFree and
         // hipHostFree synchronise the device: a driver whose batches grow -- 20, then 32 frames -- stalled four launches each time)
         if (B.d || B.h) ctx->batch_retired.emplace_back(B.d, B.h);
         B.d = B.h = nullptr;
-        const size_t want = std::max({bytes, 2 * B.cap, (size_t)256 * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t))});
+        // (the 256-frame floor is for drivers whose batches grow; it is capped at 4 MiB so that a one-frame batch at a small tile size --
+        // ts = 8 at 1080p is 32 400 tiles -- does not pin 66 MB per slot)
+        const size_t floor256 = std::min<size_t>((size_t)256 * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t)), (size_t)4 << 20);
+        const size_t want = std::max({bytes, 2 * B.cap, floor256});
         B.cap = 0;
         HIP_TRY(ctx, hipMalloc((void **)&B.d, want));
         HIP_TRY(ctx, hipHostMalloc((void **)&B.h, want));
@@ -103,9 +113,14 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         const size_t n_thr = n_own >= 24 ? std::min<size_t>({4, hw, n_own / 8}) : 1;
         if (n_thr <= 1) work(0, n_own);
         else {
+            // (nothing may unwind through the C-ABI: a thread that cannot be created -- EAGAIN, a pid limit -- leaves its share to this one)
             std::vector<std::thread> pool;
-            for (size_t i = 1; i < n_thr; i++) pool.emplace_back(work, n_own * i / n_thr, n_own * (i + 1) / n_thr);
+            size_t started = 1;
+            try {
+                for (; started < n_thr; started++) pool.emplace_back(work, n_own * started / n_thr, n_own * (started + 1) / n_thr);
+            } catch (...) {}
             work(0, n_own / n_thr);
+            if (started < n_thr) work(n_own * started / n_thr, n_own);
             for (auto &t : pool) t.join();
         }
     }

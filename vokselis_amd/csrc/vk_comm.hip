@@ -76,6 +76,11 @@ void comm_release(vk_ctx *ctx) {
 
 extern "C" {
 
+int vk_comm_available(void) {
+    if (!rccl_load()) return fail(nullptr, VK_ERR_UNSUPPORTED, g_rccl.err);
+    return VK_OK;
+}
+
 int vk_comm_unique_id(void *id128) {
     if (!id128) return VK_ERR_INVALID;
     if (!rccl_load()) return fail(nullptr, VK_ERR_UNSUPPORTED, g_rccl.err);

@@ -142,6 +142,7 @@ class BatchTileRenderer:
         self.esize = 4 if bb.format == N.OUT_RGBA32F else 2
         # Tiles travel as colour only (alpha is 1 in every pixel of this path): 6 bytes per rgba16f pixel instead of 8 on the one
         # xGMI link each peer has to the root.  Every rank constructs this object with the same arguments.
+        self._wire_before = N.WIRE_RGB if ctx.wire_pixel_bytes in (6, 12) else N.WIRE_RGBA  # restored by close()
         ctx.set_wire(wire)
         self.wire, self.ch = wire, (3 if wire == N.WIRE_RGB else 4)
         self.tile_elems = tile_size * tile_size * self.ch  # elements of one (slot, frame) record
@@ -162,25 +163,34 @@ class BatchTileRenderer:
         if transport == "rccl":
             # The library's own communicator: rank 0 makes the id, torch.distributed (already up) ships its 128 bytes.
             # ncclCommInitRank blocks until every rank has joined, so no rank may enter it unless all of them can: every
-            # rank first proves that it can load and call RCCL (its own throw-away id) and the ranks agree on that; they
-            # agree again on the outcome of the join itself.  A rank that fails raises on EVERY rank instead of leaving its
-            # peers parked inside a collective.
+            # rank first proves that it can load RCCL (vk_comm_available: no side effect -- an id made and thrown away would
+            # leave a bootstrap listener waiting for peers that never come) and the ranks agree on that; rank 0 alone makes
+            # the id; they agree again on the outcome of the join itself.  A rank that fails raises on EVERY rank instead
+            # of leaving its peers parked inside a collective, and the ranks that did join leave the communicator first.
             idbuf = (C.c_ubyte * 128)()
             why = None
             try:
-                N.check(None, N.lib().vk_comm_unique_id(idbuf))
+                N.check(None, N.lib().vk_comm_available())
+                if self.rank == 0:
+                    N.check(None, N.lib().vk_comm_unique_id(idbuf))
             except Exception as e:  # noqa: BLE001
                 why = "rank %d cannot use RCCL: %r" % (self.rank, e)
             self._agree(why, "loading RCCL")
             obj = [bytes(idbuf) if self.rank == 0 else None]
             if self.world > 1:
                 dist.broadcast_object_list(obj, src=0, group=group)
-            why = None
+            why, joined = None, False
             try:
                 N.check(ctx.handle, N.lib().vk_comm_init_rank(ctx.handle, obj[0], self.rank, self.world))
+                joined = True
             except Exception as e:  # noqa: BLE001
                 why = "rank %d could not join the communicator: %r" % (self.rank, e)
-            self._agree(why, "joining the communicator")
+            try:
+                self._agree(why, "joining the communicator")
+            except RuntimeError:
+                if joined:
+                    N.lib().vk_comm_destroy(ctx.handle)
+                raise
             self.tg = None
         elif transport == "torch":
             self.tg = TorchTileGather(group, root, via_host)
@@ -347,6 +357,9 @@ class BatchTileRenderer:
         if self.transport == "rccl":
             self.torch.cuda.synchronize()
             N.check(self.ctx.handle, N.lib().vk_comm_destroy(self.ctx.handle))
+        # the wire format is a property of the context: later users of its compact paths get back what they had
+        self.torch.cuda.synchronize()
+        self.ctx.set_wire(self._wire_before)
 
 
 def untile_reference(gathered: np.ndarray, width: int, height: int, tile_size: int, order=None, n_active=None, root_skip: int = 0) -> np.ndarray:
