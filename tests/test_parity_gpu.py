@@ -957,14 +957,30 @@ def test_compute_nearest_mode(V, O, golden, cameras):
         assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all(), lay
         first = img if first is None else first
         assert (img.view(np.uint32) == first.view(np.uint32)).all(), "the record layout changes no bit"
-    # non-multiple-of-4 dims, a tile that hangs off the image, and long steps (speculative request far outside)
+    # non-multiple-of-4 dims, a tile that hangs off the image, and long steps (speculative request far outside); the second volume has
+    # holes of exactly zero opacity with NaN normals in them (what the xor generator writes where the gradient vanishes), negative
+    # opacities and lone contributing voxels: the record kernel's skip map must not change a bit or a count
     rng = np.random.default_rng(3)
     d2 = rng.random((19, 10, 33, 4), np.float32).astype(np.float16); n2 = (rng.random((19, 10, 33, 4), np.float32) * 2 - 1).astype(np.float16)
-    for dt in (1.0, 7.5):
-        ref, rsteps, _ = O.render(cameras["xor_16x9"], d2, 96, 54, mode=O.MODE_COMPUTE_NEAREST, volume2=n2, dt_scale=dt)
-        for lay in (V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
-            img, steps, _ = gpu_render(V, cameras["xor_16x9"], d2, 96, 54, vol2=n2, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt)
-            assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dt, lay)
+    d3 = rng.random((40, 27, 33, 4), np.float32); n3 = (rng.random((40, 27, 33, 4), np.float32) * 2 - 1)
+    hole = rng.random((40, 27, 33)) < 0.97
+    hole[10:30, 5:20, 8:25] = True
+    d3[..., 3][hole] = np.where(rng.random(int(hole.sum())) < 0.5, 0.0, -0.25)
+    n3[hole & (rng.random((40, 27, 33)) < 0.5)] = np.nan
+    d3[20, 12, 16, 3] = 0.9  # a lone voxel deep inside the hole
+    d3, n3 = d3.astype(np.float16), n3.astype(np.float16)
+    for (dv, nv) in ((d2, n2), (d3, n3)):
+        for dt in (1.0, 7.5, 0.3):
+            ref, rsteps, _ = O.render(cameras["xor_16x9"], dv, 96, 54, mode=O.MODE_COMPUTE_NEAREST, volume2=nv, dt_scale=dt)
+            got = {}
+            for lay, fl in ((V.LAYOUT_PACKED, 0), (V.LAYOUT_PACKED, V.RENDER_NO_SKIP), (V.LAYOUT_LINEAR, 0)):
+                img, steps, (sr, ss) = gpu_render(V, cameras["xor_16x9"], dv, 96, 54, vol2=nv, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt, flags=fl)
+                assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dt, lay, fl)
+                got[(lay, fl)] = (img, ss)
+            assert (got[(V.LAYOUT_PACKED, 0)][0].view(np.uint32) == got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][0].view(np.uint32)).all(), dt
+            assert (got[(V.LAYOUT_PACKED, 0)][0].view(np.uint32) == got[(V.LAYOUT_LINEAR, 0)][0].view(np.uint32)).all(), dt
+            if dv is d3:
+                assert got[(V.LAYOUT_PACKED, 0)][1] <= got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][1] and (dt > 1.0 or got[(V.LAYOUT_PACKED, 0)][1] < got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][1]), dt  # (a wave-level affair: only the big hole is walked, and not with 9.6 voxels per step)
     # the reference's tile loop: (H/256+1) x (W/256+1) offsets, here with 64-px tiles incl. off-screen ones
     ctx = V.Context(128, 72, backbuffer=(128, 72), out_format=V.OUT_RGBA32F)
     try:
@@ -1524,13 +1540,20 @@ def test_xor_example_full_size(V, O):
     ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
     s_ref = int(rsteps.astype(np.int64).sum())
     assert s_ref == 21175162 and rsteps.max() <= 293 and abs(int((rsteps > 0).sum()) - 180_000) < 5_000
-    frames = {}
-    for name, lay in (("records", V.LAYOUT_AUTO), ("literal", V.LAYOUT_LINEAR)):
-        img, steps, (sr, _) = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay)
+    frames, sampled = {}, {}
+    for name, lay, fl in (("records", V.LAYOUT_AUTO, 0), ("records_noskip", V.LAYOUT_AUTO, V.RENDER_NO_SKIP), ("literal", V.LAYOUT_LINEAR, 0)):
+        img, steps, (sr, ss) = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay, flags=fl)
         assert (steps == rsteps).all() and sr == s_ref, name
         assert np.abs(img - ref).max() <= TOL, (name, np.abs(img - ref).max())
-        frames[name] = img
+        frames[name], sampled[name] = img, ss
     assert (frames["records"].view(np.uint32) == frames["literal"].view(np.uint32)).all()
+    # exact empty-space skipping of the record kernel (round 4): not a bit changes, and the steps that fetch and shade are those whose
+    # record can contribute plus a rim of one or two voxels -- the blob fills half of the cube, a ray sees far less of it
+    assert (frames["records"].view(np.uint32) == frames["records_noskip"].view(np.uint32)).all()
+    assert sampled["records_noskip"] == s_ref and sampled["literal"] == s_ref
+    a3 = den[..., 3].astype(np.float32) ** 3
+    assert 0.3 < float((a3 > 0).mean()) < 0.6
+    assert sampled["records"] < 0.75 * s_ref, (sampled["records"], s_ref)
     # three 64x64 tiles by name: centre, silhouette, hanging off the right edge
     hit = rsteps > 0
     ys, xs = np.nonzero(hit)

@@ -185,6 +185,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.flags = launch_flags(ctx, flags, true);
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
+    L.pair_walk_min = ctx->pair_walk_min;
     L.frames = reinterpret_cast<const FrameDesc *>(B.d);
     L.n_frames = n_frames;
     const int rc = dispatch_march(ctx, mode, L, flags, far_cam);

@@ -110,6 +110,7 @@ struct LaunchDesc {
     uint32_t clear_max_inactive;   // ... of whole-frame batches: inactive tiles per frame at most (0: no such blocks)
     float walk_cap;                // skip kernels: steps a walk may take in a trip in which other lanes sample (+inf: no cap)
     float walk_cap_all;            // ... and in a trip in which every lane walks
+    uint32_t pair_walk_min;        // compute twin, record kernel: a run of records that cannot contribute is walked only if it is at least this many steps long
 };
 
 // LaunchDesc::flags.  Policy and instrumentation switches of one launch, set by the host (vk_render.hip) and read by the kernels.
@@ -440,6 +441,7 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
 // a raw buffer resource sized to the array, so any sum that contains a marker is past the end and
 // the load returns zeros -- exactly the zeros this build defines for out-of-range texel loads (A.2).
 constexpr uint32_t kPairPad = 8;
+constexpr int kPairDistRadius = 60;  // the records' skip map (embedded in the records, vk_volume_kernels.hpp) saturates at kPairDistRadius + 1 voxels
 constexpr uint32_t kPairOob = 0x50000000u;  // > any record offset (array <= kPairOob bytes); 3 markers do not wrap
 __host__ __device__ __forceinline__ uint32_t pair_lut_entries(uint32_t nx, uint32_t ny, uint32_t nz) { return (nx + ny + nz + 6u * kPairPad + 3u) & ~3u; }
 

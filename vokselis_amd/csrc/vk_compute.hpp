@@ -11,7 +11,16 @@ namespace vk {
 // per step, software-pipelined: p = eye + t*dir does not depend on the loads, so the next step's
 // record is requested before this step is shaded.  A lone wave of this mode used to pay a full
 // cache-miss latency per step (<= 346 dependent steps per ray).
-template <int OUT, bool COUNT>
+//
+// SKIP (round 4): exact empty-space skipping, as the cell march has it.  A record whose opacity smoothstep(0, 0.7, a^3) is exactly 0 gives
+// w = 0: every accumulator takes +0 (the max / min of the shading launder a NaN normal, so the product is 0 x finite), A does not move, and
+// the loop's only other state is t.  Such a step need not be shaded -- provided t still takes the same sequence of rounded additions (:69) and
+// every skipped iteration passed the reference's own `t < t1` on the very same t.  The record carries, in the half get_col2 never reads
+// (normals.w), its Chebyshev distance d in voxels to the nearest record that can contribute: the samples of the next
+// m = 1 + floor((d - 2) / (voxels per step)) iterations truncate to voxels inside that empty range, so they are walked (one addition each)
+// instead of fetched and shaded.  The xor example's blob fills half of its cube and a ray leaves it by the opacity early-out or crosses
+// empty space before and after it.  Frames and per-pixel iteration counts do not change by a bit (tests: SKIP == !SKIP == the literal twin).
+template <int OUT, bool COUNT, bool SKIP = true>
 __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const LaunchDesc L, const VolumeDesc V) {
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
@@ -42,7 +51,7 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
 
     const float clr[3] = {0.023f, 0.02f, 0.02f};  // :118, clear alpha 0
     float C[3] = {clr[0], clr[1], clr[2]};
-    uint32_t n_iter = 0;
+    uint32_t n_iter = 0, n_samp = 0;
     float t0, t1;
     intersect_box(eye, dir, -1.0f, 1.0f, t0, t1);
     if (t0 < t1) {  // :123
@@ -59,6 +68,10 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
         normalize3(l2x, l2y, l2z);
         const uint32_t *luty = pair_lut + (V.nx + 2u * kPairPad), *lutz = pair_lut + (V.nx + V.ny + 4u * kPairPad);
         const __amdgpu_buffer_rsrc_t recs = cell_buffer(V.data, (uint32_t)V.max_off + 16u);
+        // steps per voxel of Chebyshev distance: after i steps a sample's voxel differs from this one's by at most floor(i * u) + 1 on every axis
+        // (u = voxels per step on the fastest axis; the + 1 is the truncation), which stays inside the empty range d - 1 for i <= (d - 2) / u;
+        // 0.01 voxel covers the rounding of p = eye + t * dir (~1e-5 voxel).  rcp: 1 ulp, far inside that margin.
+        const float inv_u = SKIP ? __builtin_amdgcn_rcpf(dt * fmaxf(fabsf(dir[0]) * hbx, fmaxf(fabsf(dir[1]) * hby, fabsf(dir[2]) * hbz))) : 0.0f;
         struct Req { float px, py, pz; u32x4_t r; };
         auto request = [&](float t) -> Req {
             Req q;
@@ -69,50 +82,99 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
             q.r = __builtin_amdgcn_raw_buffer_load_b128(recs, (int)off, 0, 0);
             return q;
         };
+        // The march alternates between two wave-level phases.
+        //  SHADE: four request buffers in a ring, three steps in flight while one is shaded (round 4; one step ahead until then): a step's
+        //   record is a miss to the Infinity Cache or HBM more often than not (268 MB of records, a new 4^3 brick every third step), ~1-2 us
+        //   against the ~0.3 us a lone wave needs to shade a step -- and a frame of this mode lasts as long as its longest rays.  p = eye +
+        //   t * dir does not depend on the loads and t takes the reference's own additions, so the steps ahead are known.  Unrolled over
+        //   the ring (no register copies).  Nothing in this loop walks: a request that a walk might have rewritten would make the compiler
+        //   wait for the newest load at every use, and the ring would hide nothing (measured: 123 us against 81 for the 720p frame).  A
+        //   lane whose record cannot contribute shades it all the same -- it adds +0 -- until EVERY live lane of the wave is at least
+        //   `walk_min` steps from anything that can contribute; then the wave leaves the loop.
+        //  WALK: every live lane hops over its run of records that cannot contribute -- the reference's own additions on t, one exposed
+        //   fetch per hop to learn the next distance -- until it meets a record that can (or is about to), or its ray ends; lanes that are
+        //   there already wait.  A ray is [empty][blob][empty] more often than not: three phases per wave.
+        // (>= 2: the wave leaves SHADE only when every live lane will take at least one hop in WALK, and WALK hands a lane back only when it
+        // would not -- each phase makes progress, whatever the knob says)
+        const float walk_min = fmaxf((float)L.pair_walk_min, 2.0f);
         float t = t0;
-        Req cur = request(t), nxt = cur;
-        for (;;) {  // :69, entered with t < t1
-            const float tn = t + dt;
-            nxt = request(tn);
-            const float px = cur.px, py = cur.py, pz = cur.pz;
-            const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
-            float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
-            float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
-            n_iter++;
-            // The shader's literal expressions (kept word for word in raymarch_compute_kernel below, which the tests hold
-            // this kernel to bit for bit) carry terms that are zero for every finite record: dot((0,-1,0), n) is -n.y,
-            // mix(shade, bl * (0,0,0.6), 0.2) has zero red and green contributions from bl, and clear.rgb * clear.a * (1 - a)
-            // is 0 * (1 - a).  IEEE arithmetic forbids the compiler to drop them (0 * x is NaN for an infinite x); with finite
-            // taps they only ever add a zero to a non-zero accumulator, so leaving them out changes no bit: 15 of the step's
-            // 85 instructions.  A volume with infinities or NaNs renders differently from the literal form.
-            float sh = fmaxf(0.0f, -n1);
-            float va = (vc3 * vc3) * vc3;
-            va = smoothstepf(0.0f, 0.7f, va);
-            float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
-            float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
-            float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
-            float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
-            float sh0 = sh * (1.0f - 0.2f);
-            float sh1 = sh0;
-            float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
-            float w = (1.0f - A) * va;
-            C[0] = C[0] + w * col0 * sh0;
-            C[1] = C[1] + w * col1 * sh1;
-            C[2] = C[2] + w * col2 * sh2;
-            A = A + w;
-            if (A >= 0.95f) break;
-            t = tn;
-            if (!(t < t1)) break;
-            cur = nxt;
+        bool alive = true;
+        Req q = request(t);  // the record of t
+        for (;;) {
+            if (SKIP) {  // ---- WALK
+                while (alive) {
+                    const uint32_t dvox = q.r.w >> 16;
+                    const float m = __builtin_floorf(fmaf((float)dvox, inv_u, -2.01f * inv_u)) + 1.0f;  // iterations, this one included, whose samples cannot contribute
+                    if (dvox == 0u || m < 2.0f) break;
+                    float c = 0.0f;
+                    do { t = t + dt; c += 1.0f; } while (c < m && t < t1);
+                    n_iter += (uint32_t)c;
+                    if (!(t < t1)) { alive = false; break; }
+                    q = request(t);
+                }
+            }
+            if (__ballot(alive) == 0ull) break;  // wave-uniform
+            // ---- SHADE
+            Req ra = q, rb, rc, rd;
+            float tl;  // the t of the last step requested
+            { const float ta = t + dt; rb = request(ta); tl = ta + dt; rc = request(tl); rd = rc; }
+            // one iteration of :69 on `cur` (the record of t), requesting into `tgt`; false: the wave leaves the loop
+            auto trip = [&](Req &cur, Req &tgt) -> bool {
+                if (SKIP) {
+                    const uint32_t dvox = cur.r.w >> 16;  // (an out-of-range load returns zeros: distance 0 -- it is shaded and adds +0)
+                    const bool deep = fmaf((float)dvox, inv_u, -2.01f * inv_u) + 1.0f >= walk_min;
+                    if (__ballot(alive && !deep) == 0ull) { q = cur; return false; }  // every live lane may walk (or none is left)
+                } else if (__ballot(alive) == 0ull) return false;
+                if (alive) {
+                    tl = tl + dt;
+                    tgt = request(tl);
+                    const float px = cur.px, py = cur.py, pz = cur.pz;
+                    const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
+                    float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
+                    float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
+                    n_iter++; n_samp++;
+                    // The shader's literal expressions (kept word for word in raymarch_compute_kernel below, which the tests hold
+                    // this kernel to bit for bit) carry terms that are zero for every finite record: dot((0,-1,0), n) is -n.y,
+                    // mix(shade, bl * (0,0,0.6), 0.2) has zero red and green contributions from bl, and clear.rgb * clear.a * (1 - a)
+                    // is 0 * (1 - a).  IEEE arithmetic forbids the compiler to drop them (0 * x is NaN for an infinite x); with finite
+                    // taps they only ever add a zero to a non-zero accumulator, so leaving them out changes no bit: 15 of the step's
+                    // 85 instructions.  A volume with infinities or NaNs renders differently from the literal form.
+                    float sh = fmaxf(0.0f, -n1);
+                    float va = (vc3 * vc3) * vc3;
+                    va = smoothstepf(0.0f, 0.7f, va);
+                    float dl = fmaxf((n0 * l1x + n1 * l1y) + n2 * l1z, 0.0f);
+                    float ss = smoothstepf(0.3f, 1.5f, (px * l2x + py * l2y) + pz * l2z);
+                    float col0 = vc0 + 3.0f * 1.0f * dl * ss, col1 = vc1 + 3.0f * 0.1f * dl * ss, col2 = vc2 + 3.0f * 0.13f * dl * ss;
+                    float bl = 0.9f * fminf(fmaxf(0.5f - 0.5f * n1, 0.0f), 1.0f);
+                    float sh0 = sh * (1.0f - 0.2f);
+                    float sh1 = sh0;
+                    float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
+                    float w = (1.0f - A) * va;
+                    C[0] = C[0] + w * col0 * sh0;
+                    C[1] = C[1] + w * col1 * sh1;
+                    C[2] = C[2] + w * col2 * sh2;
+                    A = A + w;
+                    if (A >= 0.95f) alive = false;
+                    else { t = t + dt; alive = t < t1; }
+                }
+                return true;
+            };
+            for (;;) {  // :69
+                if (!trip(ra, rd)) break;
+                if (!trip(rb, ra)) break;
+                if (!trip(rc, rb)) break;
+                if (!trip(rd, rc)) break;
+            }
+            asm volatile("" ::"v"(ra.r), "v"(rb.r), "v"(rc.r), "v"(rd.r));  // the last requests are consumed on the exit path too (keeps them ahead of the shading)
+            if (!SKIP || __ballot(alive) == 0ull) break;
         }
-        asm volatile("" ::"v"(nxt.r));  // the last request is consumed on the exit path too (keeps it ahead of the shading)
     }
     store_out<OUT>(L, pm, C[0], C[1], C[2]);
     if (COUNT) {
         if (L.steps) L.steps[(size_t)pm.y * L.W + (size_t)pm.x] = n_iter;
         if (L.counters) {
             atomicAdd(&L.counters[0], (unsigned long long)n_iter);
-            atomicAdd(&L.counters[1], (unsigned long long)n_iter);
+            atomicAdd(&L.counters[1], (unsigned long long)n_samp);
         }
     }
 }

@@ -105,6 +105,7 @@ struct vk_ctx {
     // tools/walk_cap_sweep.py: 8 / 12 -- C2 0.0806 -> 0.0728 ms per frame in batches, 0.1625 -> 0.1555 single; a fog with
     // 80 % of its 16^3 blocks knocked out 0.161 -> 0.135.  Multiples of the walk loop's four steps do best.
     uint32_t walk_cap = 8, walk_cap_all = 12;
+    uint32_t pair_walk_min = 4;  // compute twin: shortest run of empty records worth a walk (a walk restarts the request ring; tools/compute_mode.py)
     uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
     uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames
     uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements
@@ -166,5 +167,5 @@ uint32_t launch_flags(const vk_ctx *ctx, uint32_t render_flags, bool batch);
 // the kernel-instantiating TUs: each launches on ctx->stream and returns; the caller checks hipGetLastError
 void launch_cells(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool skip, bool safe, int walk /* vk_march.hpp: WalkKind */);
 void launch_staged(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, const float *cam);
-void launch_compute(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool records);
+void launch_compute(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool records, bool skip);
 void launch_procedural(vk_ctx *ctx, const vk::LaunchDesc &L, uint32_t grid, bool count, float time);

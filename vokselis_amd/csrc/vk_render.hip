@@ -79,7 +79,7 @@ int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags
         if (!std::isfinite(time)) return fail(ctx, VK_ERR_INVALID, "Uniform.time must be finite");
         launch_procedural(ctx, L, grid, count, time);
     } else if (mode == VK_MODE_COMPUTE_NEAREST) {
-        launch_compute(ctx, L, V, grid, count, ctx->vol_kind == VOL_PAIRB);  // bricked 16-byte records, or the two dense volumes (the literal twin)
+        launch_compute(ctx, L, V, grid, count, ctx->vol_kind == VOL_PAIRB, !(flags & VK_RENDER_NO_SKIP));  // bricked 16-byte records, or the two dense volumes (the literal twin)
     } else {
         // Skipping costs a distance lookup per probing trip; it only pays when there is something to skip
         // (tools/skip_crossover.py, DESIGN.md section 4: on 256^3 volumes with a share e of exactly-transparent cells
@@ -169,6 +169,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.flags = launch_flags(ctx, flags, false);
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
+    L.pair_walk_min = ctx->pair_walk_min;
     if (count && ctx->want_trace) {
         // (a per-trip log of trip_log_cap u32 per wave = trip_log_cap / 8 records of the stamps' size)
         const uint64_t recs = ctx->trip_log_cap ? n_blocks * (ctx->trip_log_cap / 8u) : n_blocks;

@@ -150,8 +150,25 @@ static int build_from_dense(vk_ctx *ctx, const void *d_src, const void *d_src2, 
         nb.vol_bytes = n_rec * 16;
         nb.vol_kind = VOL_PAIRB;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_rec + 255) / 256, 1ull << 22);
+        // scratch of the skip map: occupancy + two pass buffers, one byte per record each
+        struct PairScratch {
+            uint8_t *occ = nullptr, *tx = nullptr, *txy = nullptr;
+            ~PairScratch() { (void)hipFree(occ); (void)hipFree(tx); (void)hipFree(txy); }
+        } ps;
+        if ((rc = alloc((void **)&ps.occ, n_rec, "re-layout scratch")) || (rc = alloc((void **)&ps.tx, n_rec, "re-layout scratch")) ||
+            (rc = alloc((void **)&ps.txy, n_rec, "re-layout scratch")))
+            return rc;
         hipLaunchKernelGGL(pack_pairs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint2 *)d_src, (const uint2 *)d_src2, (uint4 *)nb.vol, nx, ny, nz,
-                           nb.nbx, nb.nby, n_rec);
+                           nb.nbx, nb.nby, n_rec, ps.occ);
+        {   // isotropic Chebyshev distance to the nearest record that can contribute, written into the records' unused eighth half
+            const uint64_t pb64 = (n_rec + 255) / 256;
+            if (pb64 >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "volume too large for one launch");
+            const uint32_t pb = (uint32_t)pb64;
+            hipLaunchKernelGGL(dist_pass_kernel, dim3(pb), dim3(256), 0, ctx->stream, ps.occ, ps.tx, nb.nbx, nb.nby, nb.nbz, 0, 0, 0, kPairDistRadius);
+            hipLaunchKernelGGL(dist_pass_kernel, dim3(pb), dim3(256), 0, ctx->stream, ps.tx, ps.txy, nb.nbx, nb.nby, nb.nbz, 1, 0, 0, kPairDistRadius);
+            hipLaunchKernelGGL(dist_pass_kernel, dim3(pb), dim3(256), 0, ctx->stream, ps.txy, ps.occ, nb.nbx, nb.nby, nb.nbz, 2, 0, 1, kPairDistRadius);
+            hipLaunchKernelGGL(embed_pair_dist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (uint4 *)nb.vol, ps.occ, n_rec);
+        }
         hipLaunchKernelGGL(build_pair_luts_kernel, dim3((padded + 255) / 256), dim3(256), 0, ctx->stream, nb.lut, nx, ny, nz, nb.nbx, nb.nby);
         if ((rc = finish("record re-layout"))) return rc;
         nb.vdesc.max_off = (int64_t)(n_rec - 1) * 16;

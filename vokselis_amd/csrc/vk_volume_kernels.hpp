@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256) void build_pair_luts_kernel(uint32_t *__restri
 }
 
 // dense x-fastest (density, normals) -> bricked 16-byte records
+// occ[id] = 0 where the record can contribute -- the shader's own opacity smoothstep(0, 0.7, a^3) (raycast_compute.wgsl:78-79) is not exactly
+// 0 -- else 255: the seed of the records' skip map (embed_pair_dist_kernel).
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2 *__restrict__ den, const uint2 *__restrict__ nrm, uint4 *__restrict__ dst,
-                                                         uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_rec) {
+                                                         uint32_t nx, uint32_t ny, uint32_t nz, uint32_t nbx, uint32_t nby, uint64_t n_rec,
+                                                         uint8_t *__restrict__ occ) {
     for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_rec; id += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t brick = id >> 6;
         const uint32_t w = (uint32_t)(id & 63u);
@@ -57,6 +60,18 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint2 *__restrict
             r = make_uint4(d.x, d.y, n.x, n.y);
         }
         dst[id] = r;
+        const float a = h2f(r.y >> 16);
+        occ[id] = smoothstepf(0.0f, 0.7f, (a * a) * a) != 0.0f ? 0 : 255;  // (a NaN opacity compares unequal: kept)
+    }
+}
+
+// The records' skip map lives INSIDE the records: the eighth half of a record is normals.w, which get_col2 never reads
+// (raycast_compute.wgsl:72-93 uses normal.rgb / .xyz / .y), so it carries the record's Chebyshev distance, in voxels, to the nearest record
+// that can contribute (0: this one can).  A nearest-neighbour step then learns how far it may skip from the one 16-byte load it makes anyway.
+__global__ __launch_bounds__(256) void embed_pair_dist_kernel(uint4 *__restrict__ recs, const uint8_t *__restrict__ dist, uint64_t n_rec) {
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_rec; id += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(recs + id) + 3;
+        *w = (*w & 0xffffu) | ((uint32_t)dist[id] << 16);
     }
 }
 
@@ -175,7 +190,7 @@ __device__ __forceinline__ uint64_t cell_index(uint32_t x, uint32_t y, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                        uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int dir, int last) {
+                                                        uint32_t nbx, uint32_t nby, uint32_t nbz, int axis, int dir, int last, int radius = kDistRadius) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t n = (uint64_t)nbx * nby * nbz * 64;
     if (id >= n) return;
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restric
     const int dim = (int)(axis == 0 ? nbx : (axis == 1 ? nby : nbz)) * 4;
     const int c0 = (int)c[axis];
     int best = in[id];
-    const int jlo = dir > 0 ? 0 : max(-kDistRadius, -c0), jhi = dir < 0 ? 0 : min(kDistRadius, dim - 1 - c0);
+    const int jlo = dir > 0 ? 0 : max(-radius, -c0), jhi = dir < 0 ? 0 : min(radius, dim - 1 - c0);
     for (int j = jlo; j <= jhi; j++) {
         const int aj = j < 0 ? -j : j;
         if (aj >= best) continue;  // cannot improve
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256) void dist_pass_kernel(const uint8_t *__restric
         const int v = in[cell_index(q[0], q[1], q[2], nbx, nby)];
         best = min(best, max(v, aj));
     }
-    if (last) best = min(best, kDistRadius + 1);
+    if (last) best = min(best, radius + 1);
     out[id] = (uint8_t)best;
 }
 
