@@ -270,6 +270,40 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def single_process_group(n_gpus, batch, s_ref, timeout_s=150):
+    """The same frames through the single-process host (vokselis_amd/host/bonsai --gpus N: one context per GPU inside a vk_group), gathered
+    over RCCL and with peer-direct stores (every GPU writes GPU 0's frames itself: no gather, no un-tile), as CHILD processes with a
+    time limit -- a path no one-GPU box can rehearse must not be able to take the line down.  Rank 0 only, after the timed windows."""
+    import re
+    import subprocess
+
+    import __graft_entry__ as G
+
+    out = {"note": "compiled host, one process, one context per GPU (vk_group_render), %d orbit frames per launch, wall time over >= 1024 frames; "
+                   "the ranks of this run idle meanwhile" % batch}
+    try:
+        G.build_host()
+    except Exception as e:  # noqa: BLE001
+        return {"error": "host build failed: %r" % (e,)}
+    exe = os.path.join(ROOT, "vokselis_amd", "_lib", "bonsai")
+    frames = max(1024, 4 * batch)
+    for name, extra in (("peer_direct", ["--peer-direct"]), ("gathered", [])):
+        cmd = [exe, "--gpus", str(n_gpus), "--frames", str(frames), "--batch", str(batch), "--size", "1920x1080", "--dt", str(DT_SCALE)] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            m = re.search(r"Avg frame time ([0-9.]+)ms", r.stdout)
+            if r.returncode == 0 and m:
+                ms = float(m.group(1))
+                out[name] = {"ms_per_step": ms, "value": s_ref / ms / 1e3, "unit": "Mray-steps/s"}
+            else:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "no result within %d s" % timeout_s}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -805,6 +839,12 @@ def main():
             out["cpu_baseline"]["s_ref_matches_gpu"] = (s_cpu == s_ref_still)
         if use_dist and btr is not None:
             btr.close()
+        if rank == 0 and world > 1 and not rehearsal and args.config == "c2" and not args.no_rotate:
+            # beside the gather to rank 0 and the rotating root: the single-process group, gathered and peer-direct
+            try:
+                out["single_process_group"] = single_process_group(world, batch, s_ref)
+            except Exception as e:  # noqa: BLE001
+                out["single_process_group"] = {"error": repr(e)}
         ctx.close()
         # the other single-GPU BASELINE configs (their own contexts: the C2 volume is gone by now)
         if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":

@@ -258,6 +258,12 @@ int vk_group_size(vk_group *g);
 vk_ctx *vk_group_ctx(vk_group *g, int i);
 int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, float dt_scale,
                     uint32_t flags, void *out_frames);
+/* Peer-direct tiles (enable != 0): every member's march stores its pixels straight into out_frames on GPU ordinals[0] over xGMI
+ * (hipDeviceEnablePeerAccess) -- no staging buffer, no gather, no un-tile pass on the root, whose fixed 5 us per 1080p frame is what
+ * bounds the gathered path at 8 GPUs.  The price: the stores cross the link as they are issued, 8 bytes at a time per lane, instead of
+ * in one bulk transfer.  Frames are bitwise the same.  Fails (and leaves the gathered path in place) when a member cannot access
+ * the root's memory. */
+int vk_group_peer_direct(vk_group *g, int enable);
 int vk_group_sync(vk_group *g);
 const char *vk_group_last_error(vk_group *g);
 

@@ -85,13 +85,28 @@ def main():
                     got = np.empty((B, H, W, 4), np.float32)
                     check(root, L.vk_device_download(root, got.ctypes.data, out, got.nbytes))
                     assert (got.view(np.uint32) == want.view(np.uint32)).all(), ("vk_group_render", n, root_skip, rep)
+                t_g, _ = stats()
+                # peer-direct (round 4): every member stores its tiles straight into the root's frames -- no staging buffer, no transfer, no
+                # un-tile; here the "peers" share GPU 0, so the stores are local, but offsets, the deal, the root's clearing strips and the
+                # cross-stream ordering are the ones a node runs.  Stale contents must not survive: poison the frames first.
+                assert L.vk_group_peer_direct(g, 1) == 0, L.vk_group_last_error(g)
+                for rep in range(2):
+                    frames_t = torch.full((B, H, W, 4), -7.0, dtype=torch.float32, device="cuda")  # (the root is GPU 0, torch's device)
+                    torch.cuda.synchronize()
+                    rc = L.vk_group_render(g, V.MODE_NAIVE_TRILINEAR, B, b"".join(cams), ts, dt, 0, C.c_void_p(frames_t.data_ptr()))
+                    assert rc == 0, L.vk_group_last_error(g)
+                    assert L.vk_group_sync(g) == 0
+                    got = frames_t.cpu().numpy()
+                    assert (got.view(np.uint32) == want.view(np.uint32)).all(), ("vk_group_render peer-direct", n, root_skip, rep)
+                assert stats()[0] == t_g, "peer-direct frames move nothing through RCCL"
+                assert L.vk_group_peer_direct(g, 0) == 0
                 check(root, L.vk_device_free(root, out))
             finally:
                 L.vk_group_destroy(g)
             t1, b1 = stats()
             assert t1 - t0 == 2 * (n - 1), ("one send/recv pair per peer and call", n, t1 - t0)
             assert fake.fake_rccl_unmatched() == 0
-            print("vk_group_render n=%d root_skip=%d wire=%s: %d frames bitwise, %d transfers, %.2f MB moved" % (n, root_skip, "rgb" if wire else "rgba", B, t1 - t0, (b1 - b0) / 1e6))
+            print("vk_group_render n=%d root_skip=%d wire=%s: %d frames bitwise (gathered and peer-direct), %d transfers, %.2f MB moved" % (n, root_skip, "rgb" if wire else "rgba", B, t1 - t0, (b1 - b0) / 1e6))
 
     # ---- (a) one context per rank: vk_comm_init_rank + vk_gather_tiles (root branch) --------------------------
     # (root: where this gather is assembled -- rank 0, or another rank as BatchTileRenderer(root="rotate") does from launch to launch)

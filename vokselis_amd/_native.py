@@ -68,6 +68,7 @@ SYMBOLS = {
     "vk_group_ctx": (_vp, [_vp, C.c_int]),
     "vk_group_render": (C.c_int, [_vp, C.c_int, _u32, _vp, _u32, _f32, _u32, _vp]),
     "vk_group_sync": (C.c_int, [_vp]),
+    "vk_group_peer_direct": (C.c_int, [_vp, C.c_int]),
     "vk_group_last_error": (C.c_char_p, [_vp]),
     "vk_device_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "vk_device_free": (C.c_int, [_vp, _vp]),

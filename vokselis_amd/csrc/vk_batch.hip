@@ -24,7 +24,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     if (!cameras || !out) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: NULL argument");
     if (n_frames == 0 || n_frames > VK_MAX_BATCH_FRAMES) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: 1..1024 frames per batch");
     if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: the step counters describe one frame; count with vk_render");
-    if (!compact && nranks != 1) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: whole frames need nranks == 1; a rank's share is compact");
+    // (compact == 0 with nranks > 1: this rank's tiles at their place in whole frames that live elsewhere -- the root's, over xGMI: vk_group_peer_direct)
     const float *cams = reinterpret_cast<const float *>(cameras);
     for (uint32_t i = 0; i < n_frames * 36u; i++)
         if (!std::isfinite(cams[i])) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: camera blob has non-finite entries");
@@ -164,7 +164,8 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     B.width = ctx->width; B.height = ctx->height; B.out_format = ctx->out_format; B.wire = ctx->wire;
     if (batch_id) *batch_id = B.id;
     // whole frames: the tiles behind a frame's active positions get their clear colour from strips at the end of the grid
-    const uint32_t clear_max_inactive = (!compact && geo_mode == VK_MODE_NAIVE_TRILINEAR && min_active < n_tiles) ? (uint32_t)n_tiles - min_active : 0u;
+    // (of a frame whose tiles several ranks write, rank 0 clears)
+    const uint32_t clear_max_inactive = (!compact && rank == 0 && geo_mode == VK_MODE_NAIVE_TRILINEAR && min_active < n_tiles) ? (uint32_t)n_tiles - min_active : 0u;
     if (slots == 0 && clear_max_inactive == 0) { HIP_TRY(ctx, hipEventRecord(B.ev, ctx->stream)); return VK_OK; }
     LaunchDesc L{};
     L.clear_max_inactive = clear_max_inactive;

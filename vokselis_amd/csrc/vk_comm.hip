@@ -160,6 +160,10 @@ struct vk_group {
     std::vector<void *> send;     // per rank: compact tiles of the current batch
     void *recv = nullptr;         // root: [n][slots][frames][ts][ts]
     size_t send_bytes = 0, recv_bytes = 0;
+    std::vector<int> ordinals;
+    bool have_comm = false;             // the communicators are made by the first gathered render: a peer-direct group never loads RCCL
+    bool peer_direct = false;           // vk_group_peer_direct: the members store into the root's frames themselves
+    std::vector<hipEvent_t> marched;    // ... and the root's stream waits for these
     std::string err;
 };
 
@@ -169,7 +173,6 @@ int vk_group_create(int n, const int *ordinals, vk_group **out) {
     if (!out) return fail(nullptr, VK_ERR_INVALID, "vk_group_create: out is NULL");
     *out = nullptr;
     if (n <= 0 || n > 64 || !ordinals) return fail(nullptr, VK_ERR_INVALID, "vk_group_create: 1..64 device ordinals");
-    if (n > 1 && !rccl_load()) return fail(nullptr, VK_ERR_UNSUPPORTED, g_rccl.err);
     vk_group *g = new (std::nothrow) vk_group();
     if (!g) return fail(nullptr, VK_ERR_OOM, "vk_group_create: host allocation failed");
     auto bail = [&](int code, const std::string &msg) { for (vk_ctx *c : g->ctx) (void)vk_ctx_destroy(c); delete g; return fail(nullptr, code, msg); };
@@ -180,14 +183,22 @@ int vk_group_create(int n, const int *ordinals, vk_group **out) {
         c->in_group = true;
         g->ctx.push_back(c);
     }
-    if (n > 1) {
-        std::vector<ncclComm_t> comms(n);
-        ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, ordinals);
-        if (r != ncclSuccess) return bail(VK_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-        for (int i = 0; i < n; i++) { g->ctx[i]->comm = comms[i]; g->ctx[i]->comm_rank = i; g->ctx[i]->comm_size = n; g->ctx[i]->comm_owned = true; }
-    }
+    g->ordinals.assign(ordinals, ordinals + n);
     g->send.assign(n, nullptr);
     *out = g;
+    return VK_OK;
+}
+
+// ncclCommInitAll over the group's GPUs, on first use (the gathered path of vk_group_render)
+static int group_ensure_comm(vk_group *g) {
+    const int n = (int)g->ctx.size();
+    if (g->have_comm || n <= 1) return VK_OK;
+    if (!rccl_load()) { g->err = g_rccl.err; return VK_ERR_UNSUPPORTED; }
+    std::vector<ncclComm_t> comms(n);
+    ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, g->ordinals.data());
+    if (r != ncclSuccess) { g->err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); return VK_ERR_HIP; }
+    for (int i = 0; i < n; i++) { g->ctx[i]->comm = comms[i]; g->ctx[i]->comm_rank = i; g->ctx[i]->comm_size = n; g->ctx[i]->comm_owned = true; }
+    g->have_comm = true;
     return VK_OK;
 }
 
@@ -199,8 +210,33 @@ int vk_group_destroy(vk_group *g) {
         if (g->send[i]) (void)hipFree(g->send[i]);
     }
     if (g->recv) { (void)hipSetDevice(g->ctx[0]->device); (void)hipFree(g->recv); }
+    for (size_t i = 0; i < g->marched.size(); i++) if (g->marched[i]) { (void)hipSetDevice(g->ctx[i]->device); (void)hipEventDestroy(g->marched[i]); }
     for (vk_ctx *c : g->ctx) (void)vk_ctx_destroy(c);
     delete g;
+    return VK_OK;
+}
+
+int vk_group_peer_direct(vk_group *g, int enable) {
+    if (!g) return VK_ERR_INVALID;
+    if (!enable) { g->peer_direct = false; return VK_OK; }
+    const int root_dev = g->ctx[0]->device;
+    for (size_t i = 1; i < g->ctx.size(); i++) {
+        const int dev = g->ctx[i]->device;
+        if (dev == root_dev) continue;  // (several members on one GPU: the rehearsal of the tests)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, root_dev) != hipSuccess || !can) { g->err = "vk_group_peer_direct: GPU " + std::to_string(dev) + " cannot access GPU " + std::to_string(root_dev); return VK_ERR_UNSUPPORTED; }
+        if (hipSetDevice(dev) != hipSuccess) { g->err = "hipSetDevice failed"; return VK_ERR_HIP; }
+        const hipError_t e = hipDeviceEnablePeerAccess(root_dev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { g->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return VK_ERR_HIP; }
+        (void)hipGetLastError();
+    }
+    if (g->marched.size() != g->ctx.size()) {
+        g->marched.assign(g->ctx.size(), nullptr);
+        for (size_t i = 0; i < g->ctx.size(); i++) {
+            if (hipSetDevice(g->ctx[i]->device) != hipSuccess || hipEventCreateWithFlags(&g->marched[i], hipEventDisableTiming) != hipSuccess) { g->err = "vk_group_peer_direct: event creation failed"; return VK_ERR_HIP; }
+        }
+    }
+    g->peer_direct = true;
     return VK_OK;
 }
 
@@ -220,6 +256,23 @@ int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *camera
         int rc = vk_render_batch(root, mode, n_frames, cameras, tile_size, 0, 1, dt_scale, flags, out_frames, 0, 0, nullptr, nullptr);
         return rc ? gfail(root, rc) : VK_OK;
     }
+    if (g->peer_direct) {
+        // Every member marches its share of every frame straight into the root's frames (whole-frame addressing, peer memory); the root, which
+        // also clears the tiles the silhouette cannot reach, waits for the others' launches on its stream.  One deal for the whole group.
+        for (int i = 1; i < n; i++) g->ctx[i]->root_skip = root->root_skip;
+        for (int i = 0; i < n; i++) {
+            int rc = vk_render_batch(g->ctx[i], mode, n_frames, cameras, tile_size, (uint32_t)i, (uint32_t)n, dt_scale, flags, out_frames, 0, 0, nullptr, nullptr);
+            if (rc) return gfail(g->ctx[i], rc);
+            if (i > 0) {
+                if (hipSetDevice(g->ctx[i]->device) != hipSuccess || hipEventRecord(g->marched[i], g->ctx[i]->stream) != hipSuccess) { g->err = "vk_group_render: event record failed"; return VK_ERR_HIP; }
+            }
+        }
+        if (hipSetDevice(root->device) != hipSuccess) { g->err = "hipSetDevice failed"; return VK_ERR_HIP; }
+        for (int i = 1; i < n; i++)
+            if (hipStreamWaitEvent(root->stream, g->marched[i], 0) != hipSuccess) { g->err = "vk_group_render: stream wait failed"; return VK_ERR_HIP; }
+        return VK_OK;
+    }
+    { int rc = group_ensure_comm(g); if (rc) return rc; }
     uint32_t cap = 0;
     if (vk_partition_slots_weighted(root->width, root->height, tile_size, (uint32_t)n, root->root_skip, &cap) != VK_OK) { g->err = "vk_group_render: bad tile size"; return VK_ERR_INVALID; }
     for (int i = 1; i < n; i++) { g->ctx[i]->root_skip = root->root_skip; g->ctx[i]->wire = root->wire; }  // one deal, one wire format for the whole group

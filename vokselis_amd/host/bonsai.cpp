@@ -2,7 +2,8 @@
 // the same Demo (volume + raycast pipeline), the same camera, rendered N frames into the backbuffer.
 //   bonsai [--frames N] [--size WxH] [--dt S] [--raw bonsai_256x256x256_uint8.raw] [--ppm out.ppm]
 //          [--f32] [--dump-rgba file] [--dump-steps file]   parity surface (rgba32f) + per-pixel trip counts, raw
-//          [--gpus N] [--batch B]                           the frame's tiles over N GPUs of this node (vk_group_*)
+//          [--gpus N] [--batch B] [--peer-direct]            the frame's tiles over N GPUs of this node (vk_group_*); --peer-direct: the GPUs
+//                                                            store into GPU 0's frames themselves instead of gather + un-tile
 //          [--camera-blobs orbits.txt out.bin]              no GPU: one 144-byte CameraUniform per "zoom pitch yaw tx ty tz aspect" line
 #include <cstdio>
 #include <algorithm>
@@ -31,7 +32,7 @@ struct Bonsai : Demo {
 
 // The frame's tiles over the node's GPUs (examples/xor/main.rs:235-254 generalised): one context per GPU inside a
 // vk_group, the volume replicated, `batch` frames per launch / gather / un-tile.
-static int run_group(int n_gpus, uint32_t frames, uint32_t batch, uint32_t w, uint32_t h) {
+static int run_group(int n_gpus, uint32_t frames, uint32_t batch, uint32_t w, uint32_t h, bool peer_direct) {
     std::vector<int> ords(n_gpus);
     for (int i = 0; i < n_gpus; i++) ords[i] = i;
     vk_group *g = nullptr;
@@ -54,8 +55,13 @@ static int run_group(int n_gpus, uint32_t frames, uint32_t batch, uint32_t w, ui
         }
         vk_ctx *root = vk_group_ctx(g, 0);
         check(root, vk_partition_wire(root, VK_WIRE_RGB));  // tiles travel as colour only: alpha is 1 in every pixel (6 bytes instead of 8 per link and pixel)
+        // --peer-direct: every GPU's march stores its tiles straight into GPU 0's frames over xGMI (no gather, no un-tile)
+        if (peer_direct && vk_group_peer_direct(g, 1) != VK_OK) throw std::runtime_error(vk_group_last_error(g));
         Camera camera(1.f, 0.5f, 1.f, {0.5f, 0.5f, 0.5f}, (float)w / (float)h);
-        std::vector<CameraUniform> cams(batch, camera.get_proj_view_matrix());
+        // every frame of a launch its own camera: consecutive frames of an orbit (yaw step 2 pi / 1024), as bench.py's headline marches them
+        std::vector<CameraUniform> cams;
+        for (uint32_t j = 0; j < batch; j++) cams.push_back(Camera(1.f, 0.5f, 1.f + 6.28318f * (float)j / 1024.f, {0.5f, 0.5f, 0.5f}, (float)w / (float)h).get_proj_view_matrix());
+        (void)camera;
         void *out = nullptr;
         check(root, vk_device_alloc(root, (size_t)batch * w * h * 8, &out));
         auto launch = [&]() { if (vk_group_render(g, VK_MODE_NAIVE_TRILINEAR, batch, cams.data(), 64, g_dt, 0, out) != VK_OK) throw std::runtime_error(vk_group_last_error(g)); };
@@ -70,6 +76,7 @@ static int run_group(int n_gpus, uint32_t frames, uint32_t batch, uint32_t w, ui
         check(root, vk_device_download(root, first.data(), out, first.size() * 2));
         uint64_t sum = 0;
         for (uint16_t v : first) sum += v;
+        std::printf("tiles: %s\n", peer_direct ? "peer-direct stores into GPU 0's frames" : "gathered over RCCL, un-tiled on GPU 0");
         std::printf("GPUs %d, %u frames per launch\nAvg frame time %.4fms over %u frames\nframe 0 half-word sum %llu\n", n_gpus, batch, ms, n_batches * batch,
                     (unsigned long long)sum);
         check(root, vk_device_free(root, out));
@@ -97,7 +104,7 @@ static int dump_camera_blobs(const std::string &in, const std::string &out) {
 int main(int argc, char **argv) {
     uint32_t frames = 100, w = 1280, h = 720, batch = 8;
     int gpus = 0;
-    bool f32 = false;
+    bool f32 = false, peer_direct = false;
     std::string ppm, dump_rgba, dump_steps;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -111,11 +118,12 @@ int main(int argc, char **argv) {
         else if (a == "--dump-rgba") dump_rgba = next();
         else if (a == "--dump-steps") dump_steps = next();
         else if (a == "--gpus") gpus = std::atoi(next());
+        else if (a == "--peer-direct") peer_direct = true;
         else if (a == "--batch") batch = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--camera-blobs") { std::string in = next(); return dump_camera_blobs(in, next()); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    if (gpus > 0) return run_group(gpus, frames, batch, w, h);
+    if (gpus > 0) return run_group(gpus, frames, batch, w, h, peer_direct);
     try {
         // examples/bonsai/main.rs:64-74: 1280x720 window, Camera::new(1., 0.5, 1., (0.5,0.5,0.5), w/h)
         Camera camera(1.f, 0.5f, 1.f, {0.5f, 0.5f, 0.5f}, (float)w / (float)h);
