@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE = 64
+PROF = "r04"  # prefix of the PMC-derived files under profiles/ this line quotes (tools/prof.sh, tools/pmc_traffic.py, tools/utilisation.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock (same guide); an f32 full-rate wave64 instruction holds a SIMD for 2 cycles,
@@ -89,7 +90,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed pre-roll that brings the GPU to its sustained clocks before the W warm-up frames")
     ap.add_argument("--no-rotate", action="store_true", help="N > 1: skip the second window with a rotating root (rotating_root in the JSON line)")
-    ap.add_argument("--headline-only", action="store_true", help="only the headline's launches (no still-camera window, no single-frame launches): what tools/prof_r3.sh profiles, so that a kernel's mean duration under rocprofv3 is the headline launch's")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline's launches (no still-camera window, no single-frame launches): what tools/prof.sh profiles, so that a kernel's mean duration under rocprofv3 is the headline launch's")
     ap.add_argument("--force-dist", action="store_true", help="use the partition + gather driver even at N = 1 (the like-for-like baseline of the N > 1 lines)")
     return ap.parse_args()
 
@@ -228,7 +229,17 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         alg_c = c_samp * cfg["b_step"] + W * H * B_RAY
         core = {"launch_ms": ms_c, "s_ref": c_ref, "s_sampled": c_samp, "Mray_steps_per_s": c_ref / ms_c / 1e3,
                 "frac": alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        return {"dense_core": core, "workload": cfg["name"], "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
+        phys = {}
+        try:  # physical HBM side of the same kernel from the PMC passes (algorithmic bytes are served from LDS: their fraction says nothing about HBM)
+            uj = json.load(open(os.path.join(ROOT, "profiles", PROF + "_utilisation.json"))).get(key, {})
+            if "hbm_bytes_per_launch" in uj:
+                phys = {"physical_hbm": {"bytes_per_launch": uj["hbm_bytes_per_launch"], "frac_of_peak_under_rocprof": uj["hbm_frac_of_peak"],
+                                         "frac_of_peak_at_this_launch_ms": uj["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "refetch_factor": uj.get("refetch_factor"), "valu_pipe_occupancy": uj.get("valu_pipe_occupancy"),
+                                         "source": "profiles/%s_utilisation.json (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes; refetch = bytes fetched / dense volume bytes)" % PROF}}
+        except Exception:
+            pass
+        return {"dense_core": core, "workload": cfg["name"], **phys, "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
                 "algorithmic_bytes_per_launch": alg, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS, "volume_setup_s": setup,
                 "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
@@ -619,17 +630,17 @@ def main():
                     "achieved_at_reference_steps": (s_ref * cfg["b_step"] + n_px * B_RAY) * n_launch_frames / (launch_ms * 1e-3) / 1e9,
                 }
                 out["roofline"]["frac_at_reference_steps"] = out["roofline"]["achieved_at_reference_steps"] / HBM_PEAK_GBS
-                # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/prof_traffic.sh)
+                # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/prof.sh, tools/pmc_traffic.py)
                 # of THIS launch shape: the same orbit, the same number of frames per launch.  No figure for another shape is
                 # scaled to this one (round 2 did that); a shape that was not profiled reports null.
-                prof = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+                prof = os.path.join(ROOT, "profiles", PROF + "_pmc_traffic.json")
                 if os.path.exists(prof) and not args.no_skip and args.layout == "auto":
                     try:
                         pj = json.load(open(prof)).get(args.config, {})
                         ent = pj.get("per_frames_per_launch", {}).get(str(n_launch_frames))
                         if ent is not None:
                             out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                            out["roofline"]["traffic_source"] = ent.get("source", "profiles/r03_pmc_traffic.json")
+                            out["roofline"]["traffic_source"] = ent.get("source", "profiles/%s_pmc_traffic.json" % PROF)
                         else:
                             out["roofline"]["traffic_note"] = "no PMC pass at %d frames per launch (profiled: %s)" % (n_launch_frames, sorted(pj.get("per_frames_per_launch", {})))
                         out["roofline"]["compulsory_GBps"] = (cfg["n"] ** 3 * (1 if cfg["fmt"] == "u8" else 2) + n_px * B_RAY * n_launch_frames) / (launch_ms * 1e-3) / 1e9
@@ -638,7 +649,7 @@ def main():
                 # the VALU side of the same kernel (it is bound by instruction issue, not by bytes): occupancy of the vector pipe and of the
                 # issue slots from the PMC passes of this launch shape, priced with the measured issue classes
                 try:
-                    uj = json.load(open(os.path.join(ROOT, "profiles", "r03_utilisation.json")))
+                    uj = json.load(open(os.path.join(ROOT, "profiles", PROF + "_utilisation.json")))
                     ent = uj.get({"c2": "default", "c4": "c4", "c5": "c5"}[args.config])
                     if ent and not args.no_skip and args.layout == "auto":
                         out["roofline"]["issue"] = {k: ent[k] for k in ("valu_pipe_occupancy", "issue_slot_occupancy", "cycles_per_valu_instruction", "hot_loop_mean_issue_cycles", "source")}
@@ -789,10 +800,12 @@ def main():
                     gb = (ss * 16 + 1280 * 720 * B_RAY) / (ms * 1e-3) / 1e9
                     extras["xor_compute_nearest_720p"] = {"launch_ms": ms, "s_ref": sr, "s_sampled": ss, "Mray_steps_per_s": sr / ms / 1e3,
                                                           "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
-                                                          # the byte roofline is the wrong yardstick for a 76-instruction step on a 16-byte record: its VALU side
-                                                          "valu_per_step": 76, "valu_mean_issue_cycles": 3.07, "valu_frac_floor": valu_floor_frac(sr, 76, 3.07, ms),
-                                                          "valu_frac_pmc": "0.37 (profiles/r03_utilisation.txt: 2.5 waves per SIMD on average -- the 720p frame is one partial round of waves "
-                                                                           "whose longest rays, 293 steps x ~90 instructions x ~6 cycles for a lone wave, set the frame time)"}
+                                                          "note": "exact empty-space skipping (s_sampled < s_ref) and a four-deep request ring since round 4; the 720p frame is one partial round "
+                                                                  "of waves and lasts as long as its longest rays (profiles/r04_compute_twin_skip_and_ring.txt)",
+                                                          "valu_per_step": 76, "valu_mean_issue_cycles": 3.07, "valu_frac_floor": valu_floor_frac(ss, 76, 3.07, ms)}
+                    pn = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, flags=V.RENDER_NO_SKIP)
+                    ms_n = time_launches(cx, lambda: pn.record(cx), it)
+                    extras["xor_compute_nearest_720p"]["no_skip"] = {"launch_ms": ms_n, "frac": (sr * 16 + 1280 * 720 * B_RAY) / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS}
                     # the same frame eight per launch: what the kernel does once the machine is full (a single 720p frame
                     # is 14 400 waves, less than two rounds of the 8192 wave slots)
                     xfr = torch.empty((8, 720, 1280, 4), dtype=torch.float16, device="cuda")

@@ -1,5 +1,5 @@
 """HBM traffic per launch of the headline kernel, per launch shape, from the PMC passes of tools/prof.sh:
-tools/pmc_traffic.py <gpurun_out/prof_r3> <config>  ->  the <config> entry of profiles/r03_pmc_traffic.json on stdout.
+tools/pmc_traffic.py <gpurun_out/prof_TAG> <config>  ->  the <config> entry of profiles/<round>_pmc_traffic.json on stdout.
 
 FETCH_SIZE and WRITE_SIZE are collected in separate rocprofv3 runs (they do not fit one pass: MI355X_MICROARCH.md, rocprofv3
 PMC slots) and are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled

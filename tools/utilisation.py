@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Issue utilisation of the march kernels from the round-3 PMC passes: for each profiled case
+"""Issue utilisation of the march kernels from the PMC passes of tools/prof.sh: for each profiled case
 
     cycles per SIMD      = GRBM_GUI_ACTIVE / 8                      (the counter sums the 8 XCDs; MI355X_MICROARCH.md, DVFS)
     cycles per VALU inst = cycles per SIMD / (SQ_INSTS_VALU / 1024 SIMDs)
@@ -11,7 +11,7 @@ profiles/r03_ubench_valu_issue_rate.txt (2 / 4 / 8 cycles), and 2.4 cycles per i
 (v_fma + s_add pairs: 4.8).  The two occupancies bound the kernel from two sides (pipe cycles, issue slots); a kernel is at its
 issue limit when either is near 1.
 
-  python tools/utilisation.py gpurun_out/prof_r3k gpurun_out/prof_r3 > profiles/r03_utilisation.txt
+  python tools/utilisation.py gpurun_out/prof_r04 --json=profiles/r04_utilisation.json > profiles/r04_utilisation.txt
 """
 import csv
 import glob
@@ -22,13 +22,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # case -> (directory under the given roots, kernel-name fragment in the counter csv, mangled-name regex for isa_hist, VALU count of the hot loop to price)
+# (kernel template arguments: raymarch_naive_kernel<VOL, SKIP, SAFE, WALK, OUT, COUNT>; raymarch_compute_records_kernel<OUT, COUNT, SKIP>)
 CASES = [
-    ("C2 headline: skip march, 64 orbit frames per launch", "default", "raymarch_naive_kernel<3, true, false, 1, false>", "raymarch_naive_kernelILi3ELb1ELb0ELi1ELb0E", None),
-    ("C2 fog, dense march, 8 frames per launch", "fogbatch", "raymarch_naive_kernel<3, false, false, 1, false>", "raymarch_naive_kernelILi3ELb0ELb0ELi1ELb0E", 88),
-    ("C5: staged u8, 3840x2160, single frame (one window per 256-thread group)", "c5", "raymarch_staged_group_kernel<10, 1, false>", "raymarch_staged_group_kernelILi10ELi1ELb0E", 50),
-    ("C4: staged f16, 1920x1080, single frame", "c4", "raymarch_staged_kernel<11, 1, false>", "raymarch_staged_kernelILi11ELi1ELb0E", 50),
-    ("compute twin (16-byte records), xor 1280x720, single frame", "xor", "raymarch_compute_records_kernel<1, false>", "raymarch_compute_records_kernelILi1ELb0E", 76),
-    ("C3: procedural, 1920x1080, single frame", "c3", "raymarch_procedural_kernel<1, false>", "raymarch_procedural_kernelILi1ELb0E", None),
+    ("C2 headline: skip march (bit-exact walk), 64 orbit frames per launch", "default", "raymarch_naive_kernel<3, true, false, 0, 1, false>", "raymarch_naive_kernelILi3ELb1ELb0ELi0ELi1ELb0E", None, None),
+    ("C2 in tolerance mode (VK_RENDER_FAST_WALK), 64 orbit frames per launch", "fastwalk", "raymarch_naive_kernel<3, true, false, 2, 1, false>", "raymarch_naive_kernelILi3ELb1ELb0ELi2ELi1ELb0E", None, None),
+    ("C2 fog, dense march, 8 frames per launch", "fogbatch", "raymarch_naive_kernel<3, false, false, 0, 1, false>", "raymarch_naive_kernelILi3ELb0ELb0ELi0ELi1ELb0E", 88, None),
+    ("C5: staged u8, 3840x2160, single frame (one window per 256-thread group)", "c5", "raymarch_staged_group_kernel<10, 1, false>", "raymarch_staged_group_kernelILi10ELi1ELb0E", 50, 2048 ** 3),
+    ("C4: staged f16, 1920x1080, single frame", "c4", "raymarch_staged_kernel<11, 1, false>", "raymarch_staged_kernelILi11ELi1ELb0E", 50, 2 * 1024 ** 3),
+    ("compute twin (16-byte records, exact skipping, 4-deep request ring), xor 1280x720, single frame", "xor", "raymarch_compute_records_kernel<1, false, true>", "raymarch_compute_records_kernelILi1ELb0ELb1E", None, None),
+    ("C3: procedural, 1920x1080, single frame", "c3", "raymarch_procedural_kernel<1, false>", "raymarch_procedural_kernelILi1ELb0E", None, None),
 ]
 
 
@@ -65,13 +67,18 @@ def loop_mix(regex, want_valu):
     return best if best else (0, 3.0, "?")
 
 
+TAG = "r04"
+
+
 def main():
-    roots = [a for a in sys.argv[1:] if not a.startswith("--json=")]
+    global TAG
+    TAG = next((a[6:] for a in sys.argv[1:] if a.startswith("--tag=")), TAG)
+    roots = [a for a in sys.argv[1:] if not a.startswith("--")]
     jpath = next((a[7:] for a in sys.argv[1:] if a.startswith("--json=")), None)
     jout = {}
     print(__doc__.split("  python tools")[0].strip())
     print()
-    for title, sub, frag, regex, want in CASES:
+    for title, sub, frag, regex, want, vol_bytes in CASES:
         d = next((os.path.join(r, sub) for r in roots if os.path.isdir(os.path.join(r, sub))), None)
         if d is None:
             continue
@@ -85,7 +92,14 @@ def main():
         lv, mean, label = loop_mix(regex, want)
         jout[sub] = {"case": title, "kernel": frag, "kernel_ms_rocprofv3": (ns or 0) / 1e6, "cycles_per_valu_instruction": cyc / valu, "hot_loop_mean_issue_cycles": mean,
                      "valu_pipe_occupancy": valu * mean / cyc, "issue_slot_occupancy": (valu + others) * 2.4 / cyc,
-                     "source": "profiles/r03_utilisation.txt (tools/utilisation.py over the PMC passes of tools/prof_r3.sh / prof_r3_kernels.sh; issue classes: profiles/r03_ubench_valu_issue_rate.txt)"}
+                     "source": "profiles/%s_utilisation.txt (tools/utilisation.py over the PMC passes of tools/prof.sh; issue classes: profiles/r03_ubench_valu_issue_rate.txt)" % TAG}
+        # physical HBM traffic of the launch: FETCH_SIZE (KiB, x 2 on gfx950: wide coalesced reads are reported at half their bytes) + WRITE_SIZE (KiB), separate passes
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c and ns:
+            hbm = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
+            jout[sub].update({"hbm_bytes_per_launch": hbm, "hbm_fetch_bytes_per_launch": 2.0 * c["FETCH_SIZE"] * 1024.0, "hbm_frac_of_peak": hbm / (ns * 1e-9) / 8.0e12})
+            if vol_bytes:
+                jout[sub]["volume_bytes"] = vol_bytes
+                jout[sub]["refetch_factor"] = 2.0 * c["FETCH_SIZE"] * 1024.0 / vol_bytes
         print("== %s" % title)
         print("   kernel %s: %.4f ms mean over %d launches (rocprofv3 --kernel-trace), %.2f GHz by GRBM_GUI_ACTIVE / 8 / time" % (frag, (ns or 0) / 1e6, calls, cyc / (ns or 1)))
         print("   cycles per SIMD %.3e | VALU instructions per SIMD %.3e -> %.2f cycles per VALU instruction" % (cyc, valu, cyc / valu))
@@ -96,6 +110,10 @@ def main():
         if "SQ_WAVE_CYCLES" in c:
             print("   waves: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES %.2f (waiting for an issue slot), SQ_WAIT_ANY / SQ_WAVE_CYCLES %.2f (waiting on a counter), mean waves per SIMD %.1f"
                   % (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_WAVE_CYCLES"] * 4.0 / 1024.0 / cyc))
+        if "hbm_bytes_per_launch" in jout[sub]:
+            j = jout[sub]
+            print("   HBM (PMC, FETCH_SIZE x 2 + WRITE_SIZE): %.3f GB per launch = %.2f of 8 TB/s physical%s"
+                  % (j["hbm_bytes_per_launch"] / 1e9, j["hbm_frac_of_peak"], (", the volume's %.2f GB fetched %.2f times" % (vol_bytes / 1e9, j["refetch_factor"])) if vol_bytes else ""))
         if c.get("SQ_LDS_IDX_ACTIVE"):
             print("   LDS: bank-conflict cycles / active cycles %.2f; LDS instructions per CU-cycle %.3f" % (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], c.get("SQ_INSTS_LDS", 0) / 256.0 / cyc))
         print()
