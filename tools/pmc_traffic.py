@@ -29,7 +29,7 @@ out = {"per_frames_per_launch": {}}
 for shape in sorted(os.listdir(root)):
     d = os.path.join(root, shape)
     line = os.path.join(d, "bench_line_under_rocprof.json")
-    if not os.path.isdir(d) or not os.path.exists(line):
+    if not os.path.isdir(d) or not os.path.exists(line) or shape not in ("default", "driver"):  # (the headline's two launch shapes; other cases have their own summaries)
         continue
     try:
         j = json.loads(open(line).read())
