@@ -609,8 +609,8 @@ def main():
                 # the headline's own window in tolerance mode (VK_RENDER_FAST_WALK), beside the bit-exact headline
                 **({"fast_walk": {"ms_per_step": fast_elapsed / timed_frames * 1e3, "value": s_ref * timed_frames / fast_elapsed / 1e6,
                                   **({"launch_ms": fast_launch_ms, "frac": alg_frame * batch / (fast_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if fast_launch_ms else {}),
-                                  "note": "same orbit window, skips advance t and p in closed form (one fma per accumulator): 99.99 % of C2's pixels within 1.1e-4 of the "
-                                          "bit-exact frame, 0.3 % of the rays take one iteration more or fewer, a few hundred pixels flip their early-out "
+                                  "note": "same orbit window, skips advance in closed form (one fma per accumulator; t kept exact): 99.99 % of C2's pixels within 1.04e-4 of "
+                                          "the bit-exact frame, 26 of 636 049 rays take one iteration more or fewer where an early-out flips "
                                           "(profiles/r04_walk_modes.txt); S_ref priced as the exact mode's"}}
                    if fast_elapsed is not None else {}),
             }

@@ -1642,12 +1642,13 @@ def test_hip_against_literal_wgsl(V, O):
 def test_fast_walk_tolerance_mode(V, O, golden, cameras, golden_volumes):
     """VK_RENDER_FAST_WALK against the ORACLE: skips advance t and p in closed form, so frames are no longer bit-identical to
     the default mode -- they stay inside the contract's 1e-4 except where a ray's last `t < t1` or its alpha >= 0.95 early-out
-    lands on the other side (profiles/r04_walk_modes.txt).  Bars: a ray's iteration count moves by at most one, on < 1 % of
-    the rays; < 0.2 % of the pixels are further than 1e-4 from the oracle; the mean difference stays below 1e-5; S_sampled
-    (integer work) within 0.2 %.  The mode changes nothing for kernels that do not skip."""
+    lands on the other side (profiles/r04_walk_modes.txt).  t is kept exact, so a ray's iteration count is the reference's unless
+    its early-out flips.  Bars: an iteration count moves by at most one, on < 0.05 % of the rays (small cubes: < 1 %); < 0.2 % of the
+    pixels are further than 1e-4 from the oracle; the mean difference stays below 1e-5; S_sampled (integer work) within 0.2 %.
+    The mode changes nothing for kernels that do not skip."""
     fast = V.RENDER_FAST_WALK
 
-    def check(img, steps, ref, rsteps, what, px_bar=2e-3, steps_bar=0.01):
+    def check(img, steps, ref, rsteps, what, px_bar=2e-3, steps_bar=5e-4):
         d = np.abs(img - ref)
         ds = np.abs(steps.astype(np.int64) - rsteps.astype(np.int64))
         hit = max(int((rsteps > 0).sum()), 1)
@@ -1665,24 +1666,21 @@ def test_fast_walk_tolerance_mode(V, O, golden, cameras, golden_volumes):
         for lay in (V.LAYOUT_PACKED_PAIRS, V.LAYOUT_PACKED):
             img, steps, (s_ref, s_samp) = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay, flags=fast)
             check(img, steps, ref, rsteps, ("standin", W, H, lay))
-            assert abs(s_ref - int(rsteps.sum())) <= 1e-4 * s_ref and abs(s_samp - int(rsamp.sum())) <= 2e-3 * s_samp
+            assert abs(s_ref - int(rsteps.sum())) <= 1e-6 * s_ref and abs(s_samp - int(rsamp.sum())) <= 2e-3 * s_samp
         # a kernel that does not skip ignores the flag: bitwise the exact frame
         a, _, _ = gpu_render(V, cam, vol, W, H, dt=dt, flags=V.RENDER_NO_SKIP | fast, want_steps=False)
         b, _, _ = gpu_render(V, cam, vol, W, H, dt=dt, flags=V.RENDER_NO_SKIP, want_steps=False)
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    # the golden vectors (32^3 volumes, 64x64: few rays, coarse cells -- a looser pixel bar) incl. the f16 volume.  A ray that crosses
-    # the cube from one face to the opposite one has a nominal iteration count that is an INTEGER in real arithmetic (n / dt_scale): which
-    # side of it the accumulated t lands on is a matter of the last ulp, so on these small cubes a tenth of the rays may take one
-    # iteration more or fewer -- through exactly transparent samples at the far face in every case here: the image bars stay.
+    # the golden vectors (32^3 volumes, 64x64: few rays, coarse cells -- looser bars) incl. the f16 volume
     g = golden["naive_64x64"]
     for key in sorted({k.rsplit("__", 1)[0] for k in g.files}):
         vname, cname, dts = key.split("__")
         for lay in (V.LAYOUT_PACKED, V.LAYOUT_PACKED_PAIRS):
             img, steps, _ = gpu_render(V, cameras[cname], golden_volumes[vname], 64, 64, dt=float(dts[2:]), layout=lay, flags=fast)
-            check(img, steps, g[key + "__rgba"], g[key + "__steps"], (key, lay), px_bar=2e-2, steps_bar=0.25)
+            check(img, steps, g[key + "__rgba"], g[key + "__steps"], (key, lay), px_bar=2e-2, steps_bar=0.01)
     gf = golden["naive_f16_64x64"]
     img, steps, _ = gpu_render(V, cameras["bonsai_1x1"], O.volume_fog_f16(32), 64, 64, dt=0.5, layout=V.LAYOUT_PACKED, flags=fast)
-    check(img, steps, gf["rgba"], gf["steps"], "f16 fog", px_bar=2e-2, steps_bar=0.25)
+    check(img, steps, gf["rgba"], gf["steps"], "f16 fog", px_bar=2e-2, steps_bar=0.01)
     # seeded cameras / dims / step sizes (the cases of test_skip_fuzz_cameras_dims_dt)
     rng = np.random.default_rng(20240611)
     for trial in range(6):
@@ -1693,4 +1691,4 @@ def test_fast_walk_tolerance_mode(V, O, golden, cameras, golden_volumes):
         dt = float(rng.choice([0.3, 0.5, 1.0]))
         ref, rsteps, _ = O.render(cam, v, W, H, dt_scale=dt)
         img, steps, _ = gpu_render(V, cam, v, W, H, dt=dt, layout=V.LAYOUT_PACKED, flags=fast)
-        check(img, steps, ref, rsteps, (trial, dims, dt), px_bar=3e-2, steps_bar=0.25)
+        check(img, steps, ref, rsteps, (trial, dims, dt), px_bar=3e-2, steps_bar=0.01)

@@ -91,10 +91,10 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 //   WALK_FMA   VK_RENDER_FAST_WALK, tolerance mode: one real addition, then m more steps as ONE fma with the rounded increment of
 //              that addition, v_1 + m (v_1 - v_0).  Inside a binade every rounded addition of the same addend moves an accumulator
 //              by the same amount, so this IS the reference's value unless the accumulator crosses a power of two during the walk;
-//              there it parts from the reference by at most (steps after the crossing) x half an ulp.  Positions agree to ~2e-4
-//              cell, frames to 1e-4 at the 99.99th percentile of C2's pixels; 0.3 % of the rays take one iteration more or fewer
-//              (the last `t < t1`), and a few hundred pixels per frame flip their alpha >= 0.95 early-out
-//              (profiles/r04_walk_modes.txt).  No cap: a walk of any length costs the same dozen instructions.
+//              there it parts from the reference by at most (steps after the crossing) x half an ulp.  That is allowed for the three
+//              coordinates only (positions agree to ~2e-4 cell); t is cut at its two or three binade boundaries and stays exact, so
+//              a ray takes the reference's number of iterations unless its alpha >= 0.95 early-out flips (profiles/r04_walk_modes.txt).
+//              No cap: a walk of any length costs the same dozen instructions.
 //   (Cutting the closed form at every binade boundary makes it exact again -- and 15 - 37 % slower than the loop: every crossing
 //   costs the lane another probing trip.  docs/history/experiments/skip_walk_binade_cut_closed_form.patch)
 enum WalkKind : int { WALK_LOOP = 0, WALK_FMA = 2 };
@@ -139,7 +139,13 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, SAFE ? 0u : (uint32_t)V.max_off + (1u << V.sh_x));
     const float t1q = __builtin_canonicalizef(t1);  // known-quiet copy: keeps a per-trip canonicalise out of the skip branch
-    const float idt = (SKIP && WALK == WALK_FMA) ? __builtin_amdgcn_rcpf(dt) : 0.0f;  // (1 ulp: it only places the last skipped step against t1)
+    // WALK_FMA: steps per unit of t, rounded DOWN: the rounded increment of t is at most dt + h, h half an ulp of t1's binade (the largest t
+    // visits); 1 / (dt + h) >= (1 - h / dt) / dt, and 2^-12 covers rcp and the products.
+    float idt = 0.0f;
+    if (SKIP && WALK == WALK_FMA) {
+        const float inv = __builtin_amdgcn_rcpf(dt), h = __uint_as_float(__float_as_uint(t1) & 0x7f800000u) * 0x1p-24f;
+        idt = fmaxf(inv * fmaf(-h, inv, 1.0f) * (1.0f - 0x1p-12f), 0.0f);
+    }
 
     // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
     // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
@@ -198,12 +204,20 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
                 float rmin = fminf(fminf(rx, ry), rz);
                 if constexpr (WALK == WALK_FMA) {
-                    // Samples j = 0 .. m are skipped: j < r keeps them inside the empty range, j < (t1 - t) / dt inside the ray (the
-                    // current sample's cell is empty: m >= 0).  The first step as the reference takes it, the rest by its increment.
-                    const float m = fmaxf(__builtin_ceilf(fminf(rmin, (t1q - t) * idt)) - 1.0f, 0.0f);
+                    // Samples j = 0 .. m are skipped (the current sample's cell is empty: m >= 0): j < r keeps them inside the empty range.
+                    // t is kept EXACT, so that the ray takes the reference's number of iterations: two real additions give the increment
+                    // every further one repeats inside t_1's binade [B, 2B) (ties included), and m stays below the steps that remain
+                    // in that binade, (2B - t_1) / d, and in the ray: t_m < t1  <=  m <= ceil(x) for any x below (t1 - t_1) / d.  (`idt`
+                    // is 1 / dt rounded down far enough for both: d <= dt + half an ulp of t1's binade.)  A ray crosses two or three
+                    // binades of t: as many walks end early and resume next trip.  The three coordinates -- a dozen binades each on the
+                    // way from 0 to 1 -- take the increment of ONE real addition and are not cut: that is where the mode is a tolerance.
                     const float t_1 = t + dt, x_1 = px + sx, y_1 = py + sy, z_1 = pz + sz;
-                    const float dt_q = t_1 - t, dx_q = x_1 - px, dy_q = y_1 - py, dz_q = z_1 - pz;
-                    t = fmaf(m, dt_q, t_1);
+                    const float t_2 = t_1 + dt;
+                    const float in_binade = fmaf(__uint_as_float(__float_as_uint(t_1) & 0x7f800000u), 2.0f, -t_1) * idt;
+                    float m = fminf(__builtin_ceilf(rmin) - 1.0f, __builtin_ceilf((t1q - t_1) * idt));
+                    m = fmaxf(fminf(m, __builtin_floorf(in_binade)), 0.0f);
+                    const float dx_q = x_1 - px, dy_q = y_1 - py, dz_q = z_1 - pz;
+                    t = fmaf(m, t_2 - t_1, t_1);
                     px = fmaf(m, dx_q, x_1); py = fmaf(m, dy_q, y_1); pz = fmaf(m, dz_q, z_1);
                     if (COUNT) { n_iter += 1u + (uint32_t)m; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                     continue;
