@@ -461,7 +461,7 @@ def test_render_batch_equals_single_frames(V, O):
                 assert (got[j].view(np.uint32) == singles[j].view(np.uint32)).all(), (mode, j)
         finally:
             ctx.close()
-    # error behaviour: counters are per frame, whole frames need one rank, capacity is checked
+    # error behaviour: counters are per frame, capacity is checked
     ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
     try:
         V.VolumeTexture(ctx, O.volume_fog_u8(16))
@@ -469,8 +469,16 @@ def test_render_batch_equals_single_frames(V, O):
         cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
         with pytest.raises(V.VokselisError):
             V.render_batch(ctx, V.RaycastPipeline(flags=V.RENDER_COUNT), [cam], buf.data_ptr())
-        with pytest.raises(V.VokselisError):
-            V.render_batch(ctx, V.RaycastPipeline(), [cam], buf.data_ptr(), nranks=2)
+        # whole-frame addressing with nranks > 1 is a rank's share written at its place in frames that live elsewhere (peer-direct tiles,
+        # vk_group_peer_direct): two "ranks" of one context fill one buffer, rank 0 clearing the tiles the silhouette cannot reach
+        V.render_batch(ctx, V.RaycastPipeline(), [cam] * 4, buf.data_ptr())
+        ctx.sync()
+        whole = buf.cpu().numpy().copy()
+        buf.fill_(-3.0); torch.cuda.synchronize()
+        for rk in (1, 0):
+            V.render_batch(ctx, V.RaycastPipeline(), [cam] * 4, buf.data_ptr(), tile_size=16, rank=rk, nranks=2)
+        ctx.sync()
+        assert (buf.cpu().numpy().view(np.uint32) == whole.view(np.uint32)).all()
         with pytest.raises(V.VokselisError):
             V.render_batch(ctx, V.RaycastPipeline(), [cam], buf.data_ptr(), compact=True, slot_capacity=0)
     finally:

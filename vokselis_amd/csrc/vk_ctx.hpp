@@ -106,6 +106,7 @@ struct vk_ctx {
     // 80 % of its 16^3 blocks knocked out 0.161 -> 0.135.  Multiples of the walk loop's four steps do best.
     uint32_t walk_cap = 8, walk_cap_all = 12;
     uint32_t pair_walk_min = 4;  // compute twin: shortest run of empty records worth a walk (a walk restarts the request ring; tools/compute_mode.py)
+    uint32_t probe_ahead = 2;    // skip kernels: request the next position's distance byte under the sample (0 never, 1 always, 2 single-frame launches)
     uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
     uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames
     uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements

@@ -99,11 +99,19 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 //   costs the lane another probing trip.  docs/history/experiments/skip_walk_binade_cut_closed_form.patch)
 enum WalkKind : int { WALK_LOOP = 0, WALK_FMA = 2 };
 
-template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false, int WALK = WALK_LOOP>
+//
+// AHEAD (LF_PROBE_AHEAD; the fast path of the skip kernels): a trip needs two fetches one after the other -- the cell's distance byte, then, if it is 0,
+// the cell -- and a heavy wave's chain of sampling trips pays both latencies per step.  With AHEAD the distance byte of the NEXT position is requested
+// while this trip's sample is evaluated: a lane that samples advances p and t (the reference's additions, :118 -- neither depends on the sample)
+// right after requesting its cell, locates the next position and requests its distance, then filters and composites.  One byte load is wasted
+// when the ray ends with that sample.  Walkers locate their new position at the end of their walk, as they did at the top of the next trip before.
+// Per ray the same operations in the same order on every variable.
+template <int VOL, bool SKIP, bool SAFE, bool COUNT, bool BOUNDED = false, int WALK = WALK_LOOP, bool AHEAD = false>
 __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const uint32_t budget, Census &cs,
                                       const uint32_t *lut = nullptr, const float walk_cap = __builtin_inff(), const float walk_cap_all = __builtin_inff()) {
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
     constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
+    static_assert(!AHEAD || (PACKED && SKIP && !SAFE && !BOUNDED), "probe-ahead: the skip kernels' fast path, unbounded");
     float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
     const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
@@ -151,6 +159,20 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
     // changes nothing observable.
     uint32_t trip = 0;  // wave-uniform: the active lanes of a wave entered the loop together
+    // AHEAD: where the ray stands, carried from trip to trip: lerp weights, cell index, and the cell's distance byte (possibly still in flight)
+    float a_fx = 0.0f, a_fy = 0.0f, a_fz = 0.0f;
+    uint32_t a_idx = 0, a_d = 0;
+    auto locate = [&](float qx, float qy, float qz) {
+        const float ux = fmaf(qx, fnx, -0.5f), uy = fmaf(qy, fny, -0.5f), uz = fmaf(qz, fnz, -0.5f);
+        a_fx = __builtin_amdgcn_fractf(ux); a_fy = __builtin_amdgcn_fractf(uy); a_fz = __builtin_amdgcn_fractf(uz);
+        a_idx = lut[cvt_floor_i32(ux) + 2] + luty[cvt_floor_i32(uy) + 2] + lutz[cvt_floor_i32(uz) + 2];
+        // A request made for a ray that turns out to have ended looks at most one step past the box: <= dt_scale cells on any axis.  The tables carry
+        // one clamped entry beyond i = -1 and i = n - 1, which covers 1.5 cells; the host sets LF_PROBE_AHEAD only for dt_scale <= 1.25
+        // (vk_render.hip), so the index is always a real cell's and the map is read inside its allocation.  (No branch around the request, and a
+        // plain global load: an exec-masked region, or a bounds-checked buffer load, gives most of the gain back.)
+        a_d = V.dist[a_idx + doff];
+    };
+    if (AHEAD) locate(px, py, pz);
     while (t < t1 && A < 0.95f && (!BOUNDED || trip < budget)) {
         if (BOUNDED) ++trip;
         if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
@@ -159,9 +181,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
             if (cs.trip_no < cs.log_cap) { le = cs.log + cs.trip_no; atomicAdd(le, 1u); }
             cs.trip_no++;
         }
-        const float ux = fmaf(px, fnx, -0.5f), uy = fmaf(py, fny, -0.5f), uz = fmaf(pz, fnz, -0.5f);
-        int ix = cvt_floor_i32(ux), iy = cvt_floor_i32(uy), iz = cvt_floor_i32(uz);
-        const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
+        const float ux = AHEAD ? 0.0f : fmaf(px, fnx, -0.5f), uy = AHEAD ? 0.0f : fmaf(py, fny, -0.5f), uz = AHEAD ? 0.0f : fmaf(pz, fnz, -0.5f);
+        int ix = AHEAD ? 0 : cvt_floor_i32(ux), iy = AHEAD ? 0 : cvt_floor_i32(uy), iz = AHEAD ? 0 : cvt_floor_i32(uz);
+        float fx = AHEAD ? a_fx : __builtin_amdgcn_fractf(ux), fy = AHEAD ? a_fy : __builtin_amdgcn_fractf(uy), fz = AHEAD ? a_fz : __builtin_amdgcn_fractf(uz);
         float c00, c10, c01, c11;  // x-lerped corners
         if (PACKED) {
             if (SAFE) { ix = med3_i32(ix, -1, mx); iy = med3_i32(iy, -1, my); iz = med3_i32(iz, -1, mz); }
@@ -174,6 +196,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 off = off < 0 ? 0 : (off > (int64_t)V.max_off ? (int64_t)V.max_off : off);
                 cptr = reinterpret_cast<const char *>(V.data) + off;
                 if (SKIP) d = V.dist[(uint64_t)(off >> V.sh_x) + doff];
+            } else if (AHEAD) {
+                coff = (uint32_t)(a_idx << V.sh_x);
+                d = a_d;
             } else {
                 // cell index (SKIP) / cell byte offset (!SKIP) from the per-axis tables; entry i + 2 is voxel i
                 const uint32_t idx = lut[ix + 2] + luty[iy + 2] + lutz[iz + 2];
@@ -220,6 +245,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     t = fmaf(m, t_2 - t_1, t_1);
                     px = fmaf(m, dx_q, x_1); py = fmaf(m, dy_q, y_1); pz = fmaf(m, dz_q, z_1);
                     if (COUNT) { n_iter += 1u + (uint32_t)m; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
+                    if (AHEAD) locate(px, py, pz);
                     continue;
                 }
                 asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
@@ -251,6 +277,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     t = t + dt;
                     if (COUNT) { n_iter++; }
                 }
+                if (AHEAD) locate(px, py, pz);
                 continue;
             }
             CellBits<VOL> cb;
@@ -259,6 +286,13 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 else { const uint4 c = *reinterpret_cast<const uint4 *>(cptr); cb.v.x = c.x; cb.v.y = c.y; cb.v.z = c.z; cb.v.w = c.w; }
             } else {
                 cb = load_cell<VOL>(cells, coff);
+            }
+            if (AHEAD) {
+                // :118 and :101's increment now -- neither depends on the sample -- then the next position's distance byte is requested
+                // under this sample's arithmetic (fx, fy, fz keep THIS position's weights)
+                px = px + sx; py = py + sy; pz = pz + sz;
+                t = t + dt;
+                locate(px, py, pz);
             }
             xlerp_cell<VOL>(cb, fx, c00, c10, c01, c11);
         } else if (BRICK9) {
@@ -317,8 +351,10 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
             // instructions, no bit changes.
             if (__ballot(a != 0.0f) == 0ull) {
                 if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
-                px = px + sx; py = py + sy; pz = pz + sz;  // :118
-                t = t + dt;
+                if (!AHEAD) {
+                    px = px + sx; py = py + sy; pz = pz + sz;  // :118
+                    t = t + dt;
+                }
                 continue;
             }
         }
@@ -333,9 +369,12 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         const float w = (1.0f - A) * a;  // :112-114
         Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
         A = A + w;
-        px = px + sx; py = py + sy; pz = pz + sz;  // :118
-        t = t + dt;
+        if (!AHEAD) {
+            px = px + sx; py = py + sy; pz = pz + sz;  // :118
+            t = t + dt;
+        }
     }
+    if (AHEAD) asm volatile("" ::"v"(a_d));  // (the last request is consumed on the exit path too)
     r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
     return t < t1 && A < 0.95f;
 }
@@ -670,7 +709,10 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     stretch = min(stretch * 2u, 512u);
                 }
             } else {
-                march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
+                if constexpr (USE_LUT) {
+                    if (L.flags & LF_PROBE_AHEAD) march<VOL, SKIP, SAFE, COUNT, false, WALK, true>(V, r, 0xffffffffu, cs, cell_lut, L.walk_cap, L.walk_cap_all);  // wave-uniform
+                    else march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, cell_lut, L.walk_cap, L.walk_cap_all);
+                } else march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, nullptr, L.walk_cap, L.walk_cap_all);
             }
         }
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);

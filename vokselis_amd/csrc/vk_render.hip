@@ -22,6 +22,7 @@ uint32_t launch_flags(const vk_ctx *ctx, uint32_t render_flags, bool batch) {
     if (!(render_flags & VK_RENDER_PROBE_ALWAYS)) f |= LF_ADAPTIVE_PROBING;
     if (ctx->wave_prio) f |= LF_WAVE_PRIORITY;
     if (batch && ctx->frame_runs) f |= LF_FRAME_RUNS;
+    if (ctx->probe_ahead == 1u || (ctx->probe_ahead == 2u && !batch)) f |= LF_PROBE_AHEAD;  // (dispatch_march drops it for dt_scale > 1.25)
     return f;
 }
 
@@ -58,6 +59,9 @@ int check_render(vk_ctx *ctx, int mode, const float *cam, float dt_scale, uint32
 // `reach_cam`: the camera whose distance decides whether the unclamped fast path is safe (the farthest of a batch).
 int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags, const float *reach_cam) {
     LaunchDesc L = L_in;
+    // probe-ahead requests the distance byte of a position one step past a ray's end: inside the index tables' padding only while a step is
+    // at most ~1.5 cells (vk_march.hpp: locate)
+    if (!(L.dt_scale <= 1.25f)) L.flags &= ~(uint32_t)LF_PROBE_AHEAD;
     const bool count = (flags & VK_RENDER_COUNT) != 0;
     VolumeDesc V = ctx->vdesc;
     V.data = ctx->vol; V.data2 = ctx->vol2; V.dist = ctx->dist;
