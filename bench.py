@@ -693,7 +693,13 @@ def main():
                 gb = (s_sampled_still * cfg["b_step"] + W * H * B_RAY) / (ms1 * 1e-3) / 1e9
                 out["single_frame"] = {"launch_ms": ms1, "launch_ms_p10": d[n1 // 10], "launch_ms_p50": d[n1 // 2], "launch_ms_p90": d[(9 * n1) // 10],
                                        "value": s_ref_still / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
-                                       "note": "one vk_render per frame, the config's camera, %d launches back to back" % n1}
+                                       "note": "one vk_render per frame (the reference's submission model), the config's camera, %d launches back to back; "
+                                               "single-frame launches of the skip kernels request the next position's distance byte under the current sample "
+                                               "(profiles/r04_probe_ahead.txt), frames bitwise those of the batched launches" % n1}
+                if args.config == "c2" and not args.no_skip and not args.fast_walk:
+                    pf = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags | V.RENDER_FAST_WALK)
+                    ms_f = time_launches(ctx, lambda: pf.record(ctx), 50, warm=10)
+                    out["single_frame"]["fast_walk"] = {"launch_ms": ms_f, "value": s_ref_still / ms_f / 1e3, "note": "the same launch in tolerance mode (VK_RENDER_FAST_WALK)"}
             except Exception as e:
                 out["single_frame"] = {"error": str(e)}
 
