@@ -617,10 +617,12 @@ __device__ __forceinline__ void clear_inactive_strip(const LaunchDesc &L, uint32
     }
 }
 
-template <int VOL, bool SKIP, bool SAFE, int WALK, int OUT, bool COUNT>
+// AHEAD: the probe-ahead trip (march<..., AHEAD>), an instantiation of its own -- it needs six more registers, and the launches that fill the machine keep the leaner kernel
+template <int VOL, bool SKIP, bool SAFE, int WALK, bool AHEAD, int OUT, bool COUNT>
 __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, const VolumeDesc V) {
     static_assert(VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16 || (!SKIP && SAFE), "linear / bricked layouts: no skip map, clamped indices");
     static_assert(SKIP || WALK == WALK_LOOP, "the closed-form walks are variants of the skip kernels");
+    static_assert(!AHEAD || (SKIP && !SAFE), "probe ahead: the skip kernels' fast path");
     if (blockIdx.x >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x - L.grid_march, threadIdx.x); return; }  // wave-uniform
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;  // wave-uniform
@@ -709,10 +711,7 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
                     stretch = min(stretch * 2u, 512u);
                 }
             } else {
-                if constexpr (USE_LUT) {
-                    if (L.flags & LF_PROBE_AHEAD) march<VOL, SKIP, SAFE, COUNT, false, WALK, true>(V, r, 0xffffffffu, cs, cell_lut, L.walk_cap, L.walk_cap_all);  // wave-uniform
-                    else march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, cell_lut, L.walk_cap, L.walk_cap_all);
-                } else march<VOL, SKIP, SAFE, COUNT, false, WALK>(V, r, 0xffffffffu, cs, nullptr, L.walk_cap, L.walk_cap_all);
+                march<VOL, SKIP, SAFE, COUNT, false, WALK, AHEAD>(V, r, 0xffffffffu, cs, USE_LUT ? cell_lut : nullptr, L.walk_cap, L.walk_cap_all);
             }
         }
         else if constexpr (VOL == VOL_B9U8 || VOL == VOL_B9F16) march_b9_stream<VOL, COUNT>(V, r, cs);
