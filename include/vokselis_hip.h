@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3
+#define VK_ABI_VERSION 4
 
 typedef struct vk_ctx vk_ctx;
 
@@ -216,6 +216,9 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
  * vk_backbuffer_resize or a new volume drops them all).  VK_RENDER_COUNT is refused.
  * Every frame is bitwise equal to the one vk_render produces for the same camera. */
 #define VK_MAX_BATCH_FRAMES 1024
+/* compact == 0 with nranks > 1 (ABI 4): this rank's tiles written at their place in whole frames [n_frames][height][width] that `out` addresses --
+ * typically another GPU's memory, mapped by hipDeviceEnablePeerAccess (vk_group_peer_direct) or HIP IPC: peer-direct tiles, no gather and no
+ * un-tile.  Rank 0 also clears the tiles the silhouette cannot reach.  The caller orders the ranks' launches against the consumer. */
 int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *cameras, uint32_t tile_size, uint32_t rank,
                     uint32_t nranks, float dt_scale, uint32_t flags, void *out, int compact, uint32_t slot_capacity,
                     uint32_t *batch_id, uint32_t *n_active_slots);
