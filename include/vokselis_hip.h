@@ -208,7 +208,7 @@ int vk_untile(vk_ctx *ctx, const void *gathered, uint32_t tile_size, uint32_t nr
  * (`cameras`: n_frames x 144-byte CameraUniform blobs, host memory) and its own heaviest-first tile order, dealt
  * position-major so the heaviest tiles of every frame start first.  A frame that is 70 % empty cannot fill 8192 wave
  * slots on its own; a batch can, and a rank holding 1/N of every frame still has n_frames/N frames of work per launch.
- *   compact == 0 (nranks must be 1): `out` receives whole frames, [n_frames][height][width] pixels of the
+ *   compact == 0: `out` receives whole frames (nranks == 1; a rank's share of them with nranks > 1, see below), [n_frames][height][width] pixels of the
  *     backbuffer's format.
  *   compact != 0: `out` receives this rank's tiles, [slot][frame][ts][ts] (slot j <-> position rank + j*nranks of
  *     that frame's order), slot < *n_active_slots <= slot_capacity: a contiguous prefix, ready for one gather.
