@@ -20,7 +20,7 @@ namespace vk {
 // m = 1 + floor((d - 2) / (voxels per step)) iterations truncate to voxels inside that empty range, so they are walked (one addition each)
 // instead of fetched and shaded.  The xor example's blob fills half of its cube and a ray leaves it by the opacity early-out or crosses
 // empty space before and after it.  Frames and per-pixel iteration counts do not change by a bit (tests: SKIP == !SKIP == the literal twin).
-template <int OUT, bool COUNT, bool SKIP = true>
+template <int OUT, bool COUNT, bool SKIP = true, int RING = 4>
 __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const LaunchDesc L, const VolumeDesc V) {
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
@@ -115,9 +115,12 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
             }
             if (__ballot(alive) == 0ull) break;  // wave-uniform
             // ---- SHADE
-            Req ra = q, rb, rc, rd;
-            float tl;  // the t of the last step requested
-            { const float ta = t + dt; rb = request(ta); tl = ta + dt; rc = request(tl); rd = rc; }
+            Req ring[RING];
+            ring[0] = q;
+            float tl = t;  // the t of the last step requested
+#pragma unroll
+            for (int k = 1; k < RING - 1; k++) { tl = tl + dt; ring[k] = request(fminf(tl, t1)); }
+            ring[RING - 1] = ring[RING - 2];
             // one iteration of :69 on `cur` (the record of t), requesting into `tgt`; false: the wave leaves the loop
             auto trip = [&](Req &cur, Req &tgt) -> bool {
                 if (SKIP) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
                 } else if (__ballot(alive) == 0ull) return false;
                 if (alive) {
                     tl = tl + dt;
-                    tgt = request(tl);
+                    tgt = request(fminf(tl, t1));  // (a request past the ray's end is never shaded: it looks at the exit face, inside the tables)
                     const float px = cur.px, py = cur.py, pz = cur.pz;
                     const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
                     float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
                 }
                 return true;
             };
-            for (;;) {  // :69
-                if (!trip(ra, rd)) break;
-                if (!trip(rb, ra)) break;
-                if (!trip(rc, rb)) break;
-                if (!trip(rd, rc)) break;
+            for (bool go = true; go;) {  // :69
+#pragma unroll
+                for (int k = 0; k < RING; k++)
+                    if (!trip(ring[k], ring[(k + RING - 1) % RING])) { go = false; break; }
             }
-            asm volatile("" ::"v"(ra.r), "v"(rb.r), "v"(rc.r), "v"(rd.r));  // the last requests are consumed on the exit path too (keeps them ahead of the shading)
+#pragma unroll
+            for (int k = 0; k < RING; k++) asm volatile("" ::"v"(ring[k].r));  // the last requests are consumed on the exit path too (keeps them ahead of the shading)
             if (!SKIP || __ballot(alive) == 0ull) break;
         }
     }

@@ -15,23 +15,27 @@ void launch_procedural(vk_ctx *ctx, const LaunchDesc &L, uint32_t grid, bool cou
     }
 }
 
-template <bool SKIP>
+template <bool SKIP, int RING>
 static void launch_records(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     const uint32_t lds = pair_lut_entries(V.nx, V.ny, V.nz) * 4u;
     if (f16) {
-        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, true, SKIP>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, false, SKIP>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, true, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, false, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     } else {
-        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, true, SKIP>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, false, SKIP>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, true, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, false, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     }
 }
 
 void launch_compute(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count, bool records, bool skip) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (records) {
-        if (skip) launch_records<true>(ctx, L, V, grid, count); else launch_records<false>(ctx, L, V, grid, count);
+        const uint32_t ring = ctx->pair_ring;
+        if (!skip) launch_records<false, 4>(ctx, L, V, grid, count);
+        else if (ring >= 8) launch_records<true, 8>(ctx, L, V, grid, count);
+        else if (ring >= 6) launch_records<true, 6>(ctx, L, V, grid, count);
+        else launch_records<true, 4>(ctx, L, V, grid, count);
         return;
     }
     if (f16) {
