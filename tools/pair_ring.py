@@ -26,12 +26,12 @@ for W, H in ((1280, 720), (1920, 1080)):
     for _ in range(200): p.record(ctx)
     ref = None
     for rep in range(2):
-        for ring in (4, 6, 8):
+        for ring in (4, 42, 6):
             ctx.set_param("pair_ring", ring)
             ms = t(ctx, lambda: p.record(ctx), 50)
             img = ctx.read_backbuffer().view(np.uint16)
             ref = img if ref is None else ref
             msb = t(ctx, lambda: V.render_batch(ctx, p, [blob] * 8, fr.data_ptr(), tile_size=64), 8) / 8
             print(json.dumps({"frame": f"{W}x{H}", "pair_ring": ring, "single_ms": round(ms, 4), "batch8_ms_per_frame": round(msb, 4), "bitwise_equal": bool((img == ref).all())}), flush=True)
-    ctx.set_param("pair_ring", 4)
+    ctx.set_param("pair_ring", 0)
     ctx.close()

@@ -20,7 +20,7 @@ namespace vk {
 // m = 1 + floor((d - 2) / (voxels per step)) iterations truncate to voxels inside that empty range, so they are walked (one addition each)
 // instead of fetched and shaded.  The xor example's blob fills half of its cube and a ray leaves it by the opacity early-out or crosses
 // empty space before and after it.  Frames and per-pixel iteration counts do not change by a bit (tests: SKIP == !SKIP == the literal twin).
-template <int OUT, bool COUNT, bool SKIP = true, int RING = 4>
+template <int OUT, bool COUNT, bool SKIP = true, int RING = 4, int REV = 1>
 __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const LaunchDesc L, const VolumeDesc V) {
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
             return q;
         };
         // The march alternates between two wave-level phases.
-        //  SHADE: four request buffers in a ring, three steps in flight while one is shaded (round 4; one step ahead until then): a step's
+        //  SHADE: RING request buffers in a ring, RING - 1 steps in flight while one is shaded (round 4; one step ahead until then): a step's
         //   record is a miss to the Infinity Cache or HBM more often than not (268 MB of records, a new 4^3 brick every third step), ~1-2 us
         //   against the ~0.3 us a lone wave needs to shade a step -- and a frame of this mode lasts as long as its longest rays.  p = eye +
         //   t * dir does not depend on the loads and t takes the reference's own additions, so the steps ahead are known.  Unrolled over
@@ -121,21 +121,32 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
 #pragma unroll
             for (int k = 1; k < RING - 1; k++) { tl = tl + dt; ring[k] = request(fminf(tl, t1)); }
             ring[RING - 1] = ring[RING - 2];
-            // one iteration of :69 on `cur` (the record of t), requesting into `tgt`; false: the wave leaves the loop
-            auto trip = [&](Req &cur, Req &tgt) -> bool {
+            // The loop body is RING iterations of :69 in a straight line -- no exit between them, no branch on `alive` (selects), every lane
+            // requests, live or not (a request past the ray's end is never shaded: it looks at the exit point, inside the tables).  Only so can the
+            // compiler count the loads in flight at each use: an exit from the middle of the body is routed through the loop's latch (the
+            // structurizer's single-exit form), which puts a path from the NEWEST request to the top of the loop, and a branch around a request
+            // makes their number unknown -- either way it waits for every load in flight before every other step (s_waitcnt vmcnt(0)).  As it
+            // is, the compiler still drains the ring once per loop iteration (it copies the buffers at the top of the loop), hence REV: the
+            // iteration is REV revolutions of the ring.  The wave decides once per iteration whether to leave; the up to RING * REV - 1 steps it
+            // shades beyond that add +0.
+            auto leave = [&](const Req &cur) -> bool {
                 if (SKIP) {
                     const uint32_t dvox = cur.r.w >> 16;  // (an out-of-range load returns zeros: distance 0 -- it is shaded and adds +0)
                     const bool deep = fmaf((float)dvox, inv_u, -2.01f * inv_u) + 1.0f >= walk_min;
-                    if (__ballot(alive && !deep) == 0ull) { q = cur; return false; }  // every live lane may walk (or none is left)
-                } else if (__ballot(alive) == 0ull) return false;
-                if (alive) {
-                    tl = tl + dt;
-                    tgt = request(fminf(tl, t1));  // (a request past the ray's end is never shaded: it looks at the exit face, inside the tables)
+                    return __ballot(alive && !deep) == 0ull;  // every live lane may walk (or none is left)
+                }
+                return __ballot(alive) == 0ull;
+            };
+            // one iteration of :69 on `cur` (the record of t), requesting into `tgt`
+            auto trip = [&](Req &cur, Req &tgt) {
+                tl = tl + dt;
+                tgt = request(fminf(tl, t1));
+                {
                     const float px = cur.px, py = cur.py, pz = cur.pz;
                     const uint32_t d0 = cur.r.x, d1 = cur.r.y, m0 = cur.r.z, m1 = cur.r.w;
                     float vc0 = h2f(d0 & 0xffffu), vc1 = h2f(d0 >> 16), vc2 = h2f(d1 & 0xffffu), vc3 = h2f(d1 >> 16);
                     float n0 = h2f(m0 & 0xffffu), n1 = h2f(m0 >> 16), n2 = h2f(m1 & 0xffffu);
-                    n_iter++; n_samp++;
+                    n_iter += alive ? 1u : 0u; n_samp += alive ? 1u : 0u;
                     // The shader's literal expressions (kept word for word in raymarch_compute_kernel below, which the tests hold
                     // this kernel to bit for bit) carry terms that are zero for every finite record: dot((0,-1,0), n) is -n.y,
                     // mix(shade, bl * (0,0,0.6), 0.2) has zero red and green contributions from bl, and clear.rgb * clear.a * (1 - a)
@@ -153,20 +164,19 @@ __global__ __launch_bounds__(64) void raymarch_compute_records_kernel(const Laun
                     float sh1 = sh0;
                     float sh2 = sh * (1.0f - 0.2f) + (bl * 0.6f) * 0.2f;
                     float w = (1.0f - A) * va;
-                    C[0] = C[0] + w * col0 * sh0;
-                    C[1] = C[1] + w * col1 * sh1;
-                    C[2] = C[2] + w * col2 * sh2;
-                    A = A + w;
-                    if (A >= 0.95f) alive = false;
-                    else { t = t + dt; alive = t < t1; }
+                    const float c0n = C[0] + w * col0 * sh0, c1n = C[1] + w * col1 * sh1, c2n = C[2] + w * col2 * sh2, An = A + w, tn = t + dt;
+                    C[0] = alive ? c0n : C[0]; C[1] = alive ? c1n : C[1]; C[2] = alive ? c2n : C[2];
+                    A = alive ? An : A;
+                    const bool on = alive && !(An >= 0.95f);  // :93-95, then :69's increment and test
+                    t = on ? tn : t;
+                    alive = on && tn < t1;
                 }
-                return true;
             };
-            for (bool go = true; go;) {  // :69
+            while (!leave(ring[0])) {  // :69
 #pragma unroll
-                for (int k = 0; k < RING; k++)
-                    if (!trip(ring[k], ring[(k + RING - 1) % RING])) { go = false; break; }
+                for (int k = 0; k < RING * REV; k++) trip(ring[k % RING], ring[(k + RING - 1) % RING]);
             }
+            q = ring[0];
 #pragma unroll
             for (int k = 0; k < RING; k++) asm volatile("" ::"v"(ring[k].r));  // the last requests are consumed on the exit path too (keeps them ahead of the shading)
             if (!SKIP || __ballot(alive) == 0ull) break;

@@ -15,27 +15,29 @@ void launch_procedural(vk_ctx *ctx, const LaunchDesc &L, uint32_t grid, bool cou
     }
 }
 
-template <bool SKIP, int RING>
+template <bool SKIP, int RING, int REV = 1>
 static void launch_records(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     const uint32_t lds = pair_lut_entries(V.nx, V.ny, V.nz) * 4u;
     if (f16) {
-        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, true, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, false, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, true, SKIP, RING, REV>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA16F, false, SKIP, RING, REV>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     } else {
-        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, true, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
-        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, false, SKIP, RING>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        if (count) hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, true, SKIP, RING, REV>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
+        else hipLaunchKernelGGL((raymarch_compute_records_kernel<OUT_RGBA32F, false, SKIP, RING, REV>), dim3(grid), dim3(64), lds, ctx->stream, L, V);
     }
 }
 
 void launch_compute(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint32_t grid, bool count, bool records, bool skip) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (records) {
-        const uint32_t ring = ctx->pair_ring;
-        if (!skip) launch_records<false, 4>(ctx, L, V, grid, count);
-        else if (ring >= 8) launch_records<true, 8>(ctx, L, V, grid, count);
-        else if (ring >= 6) launch_records<true, 6>(ctx, L, V, grid, count);
-        else launch_records<true, 4>(ctx, L, V, grid, count);
+        // request buffers x revolutions of the ring per loop iteration (vk_compute.hpp; profiles/r04_compute_twin_skip_and_ring.txt): a launch of
+        // one frame is its longest waves' chains and gains from the deeper ring; launches that fill the machine from the longer loop body
+        const uint32_t ring = ctx->pair_ring ? ctx->pair_ring : (L.n_frames > 1 ? 42u : 6u);
+        if (!skip) launch_records<false, 4, 1>(ctx, L, V, grid, count);
+        else if (ring == 42) launch_records<true, 4, 2>(ctx, L, V, grid, count);
+        else if (ring == 6) launch_records<true, 6, 1>(ctx, L, V, grid, count);
+        else launch_records<true, 4, 1>(ctx, L, V, grid, count);
         return;
     }
     if (f16) {
