@@ -1003,6 +1003,63 @@ def test_compute_nearest_mode(V, O, golden, cameras):
         ctx.close()
 
 
+def test_compute_fuzz_cameras_dims_dt(V, O):
+    """Seeded fuzz of the compute twin's record kernel (request ring + exact skipping): random dims, blobs with exactly-zero and negative
+    opacity around them and NaN normals in the holes, cameras outside / inside / axis-aligned, image sizes and dt_scale.  Skip == no skip ==
+    the literal twin bitwise, iteration counts identical to the oracle; the same frames in one launch of several (the ring's other shape)."""
+    import torch
+
+    rng = np.random.default_rng(20261004)
+    for trial in range(12):
+        dims = tuple(int(x) for x in rng.integers(8, 48, 3))  # (nx, ny, nz)
+        W, H = int(rng.integers(32, 96)), int(rng.integers(32, 96))
+        z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+        den = rng.random(x.shape + (4,), np.float32)
+        op = np.where(rng.random(x.shape) < 0.5, 0.0, -0.25).astype(np.float32)
+        for _ in range(3):
+            c = rng.uniform(0.2, 0.8, 3) * np.array(dims); rad = rng.uniform(2, 0.35 * min(dims))
+            d2 = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2
+            op = np.where(d2 < rad * rad, rng.uniform(0.2, 1.0), op)
+        den[..., 3] = op
+        nrm = (rng.random(x.shape + (4,), np.float32) * 2 - 1)
+        nrm[(op <= 0) & (rng.random(x.shape) < 0.5)] = np.nan
+        den, nrm = den.astype(np.float16), nrm.astype(np.float16)
+        kind = trial % 3
+        if kind == 0:
+            cam_args = (float(rng.uniform(2.0, 4.0)), float(rng.uniform(-1.3, 1.3)), float(rng.uniform(0, 6.28)), (0.0, 0.0, 0.0), W / H)
+        elif kind == 1:  # eye inside the box
+            cam_args = (float(rng.uniform(0.1, 0.6)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0, 6.28)), tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3)), W / H)
+        else:            # axis-aligned
+            cam_args = (3.0, 0.0, float(rng.integers(0, 4)) * 1.5707963, (0.0, 0.0, 0.0), 1.0)
+        dt = float(rng.choice([0.3, 1.0, 2.5]))
+        cam = O.camera_blob(*cam_args)
+        ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm, dt_scale=dt)
+        got = []
+        for lay, fl in ((V.LAYOUT_PACKED, 0), (V.LAYOUT_PACKED, V.RENDER_NO_SKIP), (V.LAYOUT_LINEAR, 0)):
+            img, steps, _ = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt, flags=fl)
+            assert (steps == rsteps).all() and np.abs(img - ref).max() <= TOL, (trial, dims, cam_args, dt, lay, fl)
+            got.append(img)
+        assert (got[0].view(np.uint32) == got[1].view(np.uint32)).all() and (got[0].view(np.uint32) == got[2].view(np.uint32)).all(), (trial, dims, cam_args, dt)
+        # three frames in one launch against the three single launches
+        cams = [cam] + [O.camera_blob(cam_args[0], cam_args[1], cam_args[2] + 0.3 * k, cam_args[3], cam_args[4]) for k in (1, 2)]
+        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+        try:
+            V.VolumeTexture(ctx, den, nrm, layout=V.LAYOUT_PACKED)
+            pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, dt_scale=dt)
+            singles = []
+            for c in cams:
+                ctx.set_camera_blob(c); pipe.record(ctx); singles.append(ctx.read_backbuffer().copy())
+            assert (singles[0].view(np.uint32) == got[0].view(np.uint32)).all(), (trial, "the default policy's frame")
+            frames = _synced(torch.zeros((3, H, W, 4), dtype=torch.float32, device="cuda"))
+            V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=32)
+            ctx.sync()
+            out = frames.cpu().numpy()
+            for k in range(3):
+                assert (out[k].view(np.uint32) == singles[k].view(np.uint32)).all(), (trial, dims, cam_args, dt, "frame", k)
+        finally:
+            ctx.close()
+
+
 def test_procedural_mode(V, O, golden, cameras):
     """C3: no volume, density from xor.wgsl's noise_volume at the sample position.  Trip counts are
     integer work and must be identical; RGBA within 1e-4 (measured ~1e-7: the specified sine is shared)."""
