@@ -32,8 +32,9 @@ void launch_compute(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint3
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     if (records) {
         // request buffers x revolutions of the ring per loop iteration (vk_compute.hpp; profiles/r04_compute_twin_skip_and_ring.txt): a launch of
-        // one frame is its longest waves' chains and gains from the deeper ring; launches that fill the machine from the longer loop body
-        const uint32_t ring = ctx->pair_ring ? ctx->pair_ring : (L.n_frames > 1 ? 42u : 6u);
+        // one frame that does not fill the machine (720p: 14 400 waves) is its longest waves' chains and gains from the deeper ring; launches
+        // that do (1080p: 32 400; several frames) from the longer loop body
+        const uint32_t ring = ctx->pair_ring ? ctx->pair_ring : ((L.n_frames > 1 || L.n_blocks >= 24000u) ? 42u : 6u);
         if (!skip) launch_records<false, 4, 1>(ctx, L, V, grid, count);
         else if (ring == 42) launch_records<true, 4, 2>(ctx, L, V, grid, count);
         else if (ring == 6) launch_records<true, 6, 1>(ctx, L, V, grid, count);
