@@ -227,8 +227,8 @@ def test_golden_volumes_rebuild(tmp_path, golden_volumes):
     from conftest import GOLDEN, adversarial_volumes
 
     G.main(str(tmp_path))
-    # (volume_png_pin.npz comes from oracle/volume_png.py and is re-derived by test_volume_png_pin)
-    names = sorted(n for n in os.listdir(GOLDEN) if n.endswith(".npz") and not n.startswith("volume_png"))
+    # (volume_png_pin.npz / bonsai_png_colours.npz come from oracle/volume_png.py / bonsai_png.py and are re-derived by their own tests)
+    names = sorted(n for n in os.listdir(GOLDEN) if n.endswith(".npz") and not n.startswith(("volume_png", "bonsai_png")))
     assert names == sorted(n for n in os.listdir(tmp_path) if n.endswith(".npz"))
     for n in names:
         a, b = np.load(os.path.join(GOLDEN, n)), np.load(os.path.join(tmp_path, n))
@@ -324,3 +324,34 @@ def test_volume_png_pin(O):
     b1 = VP._bbox(VP.blurred_ds(frame))
     ratio = (b1[3] - b1[2]) / (b0[3] - b0[2])
     assert 1.35 < ratio < 1.75, ratio
+
+
+def test_bonsai_png_palette_pin(O):
+    """The second reference-held pin, for the naive path (oracle/bonsai_png.py): every colour of the reference's `bonsai.png` is a convex
+    combination of black and the oracle's palette curve -- uniform volumes v = 0 .. 255 under raycast_naive.wgsl:101-123 -- once the capture's
+    present pass is read as one more linear_to_srgb; its greenest colour (the inside of the pot) IS a point of that curve."""
+    import os
+
+    from oracle import bonsai_png as BP
+
+    pin = BP.load_pin()
+    sample, ext = pin["sample"], pin["extremes"]
+    assert sample.shape == (BP.SAMPLE, 3) and ext.shape == (27, 3)
+    if os.path.exists(BP.REF_PNG):
+        from PIL import Image
+
+        png = np.array(Image.open(BP.REF_PNG).convert("RGB"))
+        s2, e2, n_nz = BP.colours_of(png)
+        assert (s2 == sample).all() and (e2 == ext).all() and n_nz == int(pin["non_black"])
+        assert (png[0, 0] == 0).all() and (png[0, 0] == pin["background"]).all()  # LoadOp::Clear(BLACK), examples/bonsai/main.rs:41
+    assert tuple(int(v) for v in ext[26]) == BP.GREENEST
+    curve = BP.oracle_curve()
+    assert curve.shape == (256, 3) and (curve[:20] == 0).all()  # values up to 0.1 * 255 are exactly transparent
+    hull = BP.hull_of(curve)
+    both = np.vstack([sample, ext])
+    assert BP.inside_share(both, hull, BP.decode_double_srgb) >= BP.BAR_INSIDE
+    assert BP.inside_share(both, hull, BP.decode_aces_srgb) <= BP.BAR_INSIDE_ACES  # (0.77 on the whole capture: HEAD's tone map is not what took it)
+    v, d = BP.nearest_on_curve(BP.GREENEST, curve)
+    assert d <= BP.BAR_GREENEST and 170 <= v <= 190, (v, d)
+    # nothing a backbuffer value <= 1 can produce through ACES + sRGB exceeds 232; the capture goes up to 249
+    assert int(np.round(255 * BP.present_srgb(np.float32(2.51 + 0.03) / np.float32(2.43 + 0.59 + 0.14)))) <= 232 < int(both.max())

@@ -1594,6 +1594,37 @@ def test_volume_png_pin_hip(V, O):
         assert abs(m["corr"] - float(pin["corr"])) < 5e-3 and abs(m["mean_abs"] - float(pin["mean_abs"])) < 0.05, m
 
 
+def test_bonsai_png_pin_hip(V, O):
+    """The naive path's reference-held pin through the HIP kernels (oracle/bonsai_png.py): the palette curve -- uniform volumes v = 0 .. 255
+    under a saturating ray -- rendered by vk_render equals the oracle's, the colours of the reference's `bonsai.png` lie inside its hull, and
+    the capture's greenest colour is the HIP curve's point for v = 179 to one LSB."""
+    from oracle import bonsai_png as BP
+
+    pin = BP.load_pin()
+    W, H = 16, 9
+    ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        pipe = V.RaycastPipeline(dt_scale=1.0)
+
+        def one(v):
+            V.VolumeTexture(ctx, np.full((32, 32, 32), v, np.uint8))
+            ctx.update()
+            pipe.record(ctx)
+            return ctx.read_backbuffer()[H // 2, W // 2].copy()
+
+        curve = BP.curve_backbuffer(one)
+    finally:
+        ctx.close()
+    ref = BP.oracle_curve()
+    assert np.abs(curve - ref).max() <= TOL
+    hull = BP.hull_of(curve)
+    both = np.vstack([pin["sample"], pin["extremes"]])
+    assert BP.inside_share(both, hull, BP.decode_double_srgb) >= BP.BAR_INSIDE
+    assert BP.inside_share(both, hull, BP.decode_aces_srgb) <= BP.BAR_INSIDE_ACES
+    v, d = BP.nearest_on_curve(BP.GREENEST, curve)
+    assert d <= BP.BAR_GREENEST and 170 <= v <= 190, (v, d)
+
+
 def test_xor_example_full_size(V, O):
     """The reference's own xor configuration at its own size: 256^3 pair volume, 1280x720, camera (3, -0.5, 1, 0)
     (examples/xor/main.rs:232-233,273-279) -- the frame bench.py times as `xor_compute_nearest_720p`.  Every pixel and every
