@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE config to run (the metric is quoted on c2)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 64 for c2 -- 32 N at N > 1, at most 256 --, 4 for c4 and c5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 128 for c2 -- 32 N at N > 1, at least 128, at most 256 --, 4 for c4 and c5)")
     ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
     ap.add_argument("--fast-walk", action="store_true", help="run the timed path in VK_RENDER_FAST_WALK (tolerance mode: skips advance in closed form; not bit-exact)")
     ap.add_argument("--layout", default="auto", choices=["auto", "pairs", "packed", "bricked", "staged"], help="volume layout (auto: the library's choice)")
@@ -331,11 +331,11 @@ def main():
     args.gpus = world  # (under a launcher the world it made is what runs)
     cfg = CONFIGS[args.config]
     W, H = cfg["W"], cfg["H"]
-    batch = args.batch or {"c2": 64, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 frames per launch: 0.0677 / 0.0659 / 0.0644 ms)
+    batch = args.batch or {"c2": 128, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 / 256 frames per launch: 0.0677 / 0.0659 / 0.0644 / 0.0645 ms)
     if not args.batch and args.config == "c2" and world > 1:
         # a rank's launch covers 1 / N of every frame: more frames per launch keep it from paying the launch's tail N times as
         # often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at 16 / 32 / 64 / 128 frames per launch)
-        batch = min(256, max(64, 32 * world))
+        batch = min(256, max(128, 32 * world))
     batch = max(1, batch)
     # ONE contiguous timed window (>= 100 timed frames): M = the multiple of K that covers max(100, four launches)
     # -- march, wire and un-tile of different launches only overlap when a window holds several of them -- the same rule at
