@@ -266,7 +266,9 @@ int vk_group_render(vk_group *g, int mode, uint32_t n_frames, const void *camera
  * (hipDeviceEnablePeerAccess) -- no staging buffer, no gather, no un-tile pass on the root, whose fixed 5 us per 1080p frame is what
  * bounds the gathered path at 8 GPUs.  The price: the stores cross the link as they are issued, 8 bytes at a time per lane, instead of
  * in one bulk transfer.  Frames are bitwise the same.  Fails (and leaves the gathered path in place) when a member cannot access
- * the root's memory. */
+ * the root's memory.  The members write out_frames from their OWN streams (the root's stream waits for them, not they for it): a second
+ * vk_group_render into the same out_frames must not be issued before whatever reads the first one's frames on the root has finished
+ * (vk_group_sync, or alternate two buffers). */
 int vk_group_peer_direct(vk_group *g, int enable);
 int vk_group_sync(vk_group *g);
 const char *vk_group_last_error(vk_group *g);
