@@ -42,6 +42,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE = 64
+
+
+def tile_of(cfg) -> int:
+    """Tile size of the batched launches: 64 (C2: 0.0689 / 0.0647 / 0.0671 ms per frame at 32 / 64 / 128; C5 the same at 32 and 64); the f16
+    staged march gains from finer tiles (C4, four frames per launch: 1.50 ms per frame at 32 against 1.556 at 64)."""
+    return 32 if cfg["fmt"] != "u8" else 64
+
+
 PROF = "r04"  # prefix of the PMC-derived files under profiles/ this line quotes (tools/prof.sh, tools/pmc_traffic.py, tools/utilisation.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
@@ -215,7 +223,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         # share their brick fetches in L2 / Infinity Cache and run up to 20 % faster than any real frame stream
         # (tools/big_batch_orbit.py); unrelated views in one launch gain nothing over single launches
         blobs = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(nb)]
-        ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, blobs, fr.data_ptr(), tile_size=TILE), 3, warm=1) / nb
+        ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, blobs, fr.data_ptr(), tile_size=tile_of(cfg)), 3, warm=1) / nb
         del fr
         dims = (V.native.C.c_uint32 * 3)()
         lay, nbytes = V.native.C.c_int(), V.native.C.c_size_t()
@@ -330,6 +338,8 @@ def main():
         os.environ["VK_BENCH_TRANSPORT"] = "torch"
     args.gpus = world  # (under a launcher the world it made is what runs)
     cfg = CONFIGS[args.config]
+    global TILE
+    TILE = tile_of(cfg)
     W, H = cfg["W"], cfg["H"]
     batch = args.batch or {"c2": 128, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 / 256 frames per launch: 0.0677 / 0.0659 / 0.0644 / 0.0645 ms)
     if not args.batch and args.config == "c2" and world > 1:

@@ -244,6 +244,7 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
     else if (n == "walk_cap") ctx->walk_cap = (uint32_t)value;
     else if (n == "walk_cap_all") ctx->walk_cap_all = (uint32_t)value;
+    else if (n == "render_tile") ctx->render_tile = ((uint32_t)value & ~7u);
     else if (n == "pair_ring") ctx->pair_ring = (uint32_t)value;
     else if (n == "probe_ahead") ctx->probe_ahead = (uint32_t)value;
     else if (n == "pair_walk_min") ctx->pair_walk_min = (uint32_t)std::min(std::max(2.0, value), 1e6);

@@ -105,6 +105,7 @@ struct vk_ctx {
     // tools/walk_cap_sweep.py: 8 / 12 -- C2 0.0806 -> 0.0728 ms per frame in batches, 0.1625 -> 0.1555 single; a fog with
     // 80 % of its 16^3 blocks knocked out 0.161 -> 0.135.  Multiples of the walk loop's four steps do best.
     uint32_t walk_cap = 8, walk_cap_all = 12;
+    uint32_t render_tile = 0;    // vk_render: tile size of the launch order (0: 64, 32 for the staged march)
     uint32_t pair_ring = 0;      // compute twin: request buffers in the SHADE ring (4, 6; 42: 4 buffers, two revolutions per loop iteration; 0: by launch shape)
     uint32_t pair_walk_min = 4;  // compute twin: shortest run of empty records worth a walk (a walk restarts the request ring; tools/compute_mode.py)
     uint32_t probe_ahead = 2;    // skip kernels: request the next position's distance byte under the sample (0 never, 1 always, 2 single-frame launches)
