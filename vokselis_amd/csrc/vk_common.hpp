@@ -146,8 +146,8 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t b) {
 // Issue priority by the length of the wave's longest ray, in quarters of the longest possible march (n / dt_scale
 // trips): a frame is one or two rounds of resident waves, and under even sharing of a SIMD's issue slots the longest
 // waves -- started first, finished last -- set the frame time while the short ones leave early.  Speed only.
-__device__ __forceinline__ void set_wave_priority(bool hit, float t0, float t1, float dt, float full) {
-    const float trips = hit ? (t1 - t0) / dt : 0.0f;
+__device__ __forceinline__ void set_wave_priority(bool hit, uint32_t left, float full) {
+    const float trips = hit ? (float)left : 0.0f;
     if (__ballot(trips > 0.75f * full)) __builtin_amdgcn_s_setprio(3);
     else if (__ballot(trips > 0.5f * full)) __builtin_amdgcn_s_setprio(2);
     else if (__ballot(trips > 0.25f * full)) __builtin_amdgcn_s_setprio(1);

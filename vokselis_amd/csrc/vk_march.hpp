@@ -3,6 +3,7 @@
 #pragma once
 
 #include "vk_common.hpp"
+#include "vk_trips.hpp"
 
 namespace vk {
 
@@ -56,13 +57,24 @@ __device__ __forceinline__ void xlerp_cell(const CellBits<VOL> &cb, float fx, fl
     }
 }
 
+// -k for a walk of k = ceil(r) steps, 1 <= k <= iterations left (nleft = -left < 0): floor(-r) in one conversion (it saturates), clamped in one v_med3
+__device__ __forceinline__ int walk_steps_neg(float r, int nleft) {
+    int k;
+    asm("v_cvt_flr_i32_f32_e64 %0, -%1\n\tv_med3_i32 %0, %0, %2, -1" : "=&v"(k) : "v"(r), "v"(nleft));
+    return k;
+}
+
 // ---- the march, resumable ---------------------------------------------------------------------
-// Everything a ray needs to continue: the accumulators of the reference loop (t, p, alpha, colour
-// sums), its per-ray constants and where its pixel goes.  64 bytes.
+// Everything a ray needs to continue: the accumulators of the reference loop (p, alpha, colour sums), its per-ray constants and
+// where its pixel goes.  64 bytes.
+// The loop variable of raycast_naive.wgsl:101 is not among them.  t feeds nothing but its own test `t < t1`, so the march carries
+// `left`, the number of iterations the loop has still to make -- count_trips() (vk_trips.hpp) computes the loop's trip count from
+// (t0, t1, dt) exactly, rounding by rounding, once per ray (round 5).
 struct RayState {
-    float t, t1, dt, px, py, pz, sx, sy, sz, A, Gr, Gg, Gb;
+    uint32_t left;       // iterations of :101 not made yet
+    float px, py, pz, sx, sy, sz, A, Gr, Gg, Gb;
     uint32_t out;        // pixel index into the launch's output
-    uint32_t pad[2];
+    uint32_t pad[4];
 };
 static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
 
@@ -86,15 +98,15 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 // non-negative partial index and LDS reads outside the allocation return 0, so any combination stays
 // inside the cell array: no clamp.
 //
-// WALK: how a run of exactly transparent steps advances the reference's accumulators (t += dt, p += s: raycast_naive.wgsl:101,118).
-//   WALK_LOOP  the additions themselves, four per loop iteration, capped per trip: bit-exact, the default.
-//   WALK_FMA   VK_RENDER_FAST_WALK, tolerance mode: one real addition, then m more steps as ONE fma with the rounded increment of
+// WALK: how a run of k exactly transparent steps advances the reference's position (p += s, k times: raycast_naive.wgsl:118; the loop
+// variable of :101 is the integer `left`, see RayState: left -= k).
+//   WALK_LOOP  the additions themselves, four steps per loop iteration, capped per trip: bit-exact, the default.
+//   WALK_FMA   VK_RENDER_FAST_WALK, tolerance mode: one real addition, then k - 1 more steps as ONE fma with the rounded increment of
 //              that addition, v_1 + m (v_1 - v_0).  Inside a binade every rounded addition of the same addend moves an accumulator
-//              by the same amount, so this IS the reference's value unless the accumulator crosses a power of two during the walk;
-//              there it parts from the reference by at most (steps after the crossing) x half an ulp.  That is allowed for the three
-//              coordinates only (positions agree to ~2e-4 cell); t is cut at its two or three binade boundaries and stays exact, so
-//              a ray takes the reference's number of iterations unless its alpha >= 0.95 early-out flips (profiles/r04_walk_modes.txt).
-//              No cap: a walk of any length costs the same dozen instructions.
+//              by the same amount, so this IS the reference's value unless the coordinate crosses a power of two during the walk;
+//              there it parts from the reference by at most (steps after the crossing) x half an ulp (positions agree to ~2e-4 cell).
+//              The number of iterations is the reference's whatever the walk does (`left` is exact), unless the alpha >= 0.95
+//              early-out flips (profiles/r04_walk_modes.txt).  No cap: a walk of any length costs the same dozen instructions.
 //   (Cutting the closed form at every binade boundary makes it exact again -- and 15 - 37 % slower than the loop: every crossing
 //   costs the lane another probing trip.  docs/history/experiments/skip_walk_binade_cut_closed_form.patch)
 enum WalkKind : int { WALK_LOOP = 0, WALK_FMA = 2 };
@@ -112,8 +124,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     constexpr bool PACKED = (VOL == VOL_P8 || VOL == VOL_P16 || VOL == VOL_PF16);
     constexpr bool BRICK9 = (VOL == VOL_B9U8 || VOL == VOL_B9F16);
     static_assert(!AHEAD || (PACKED && SKIP && !SAFE && !BOUNDED), "probe-ahead: the skip kernels' fast path, unbounded");
-    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
-    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    float px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    int nleft = -(int)r.left;  // minus the iterations left (counts up to 0: a walk's -k = floor(-r) comes out of one conversion)
+    const float sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
     uint32_t &n_iter = cs.n_iter, &n_samp = cs.n_samp, &w_outer = cs.w_outer, &w_inner = cs.w_inner, &w_sample = cs.w_sample, &n_look = cs.n_look;
     const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
@@ -132,10 +145,8 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         // (x n_i cells); doubled, plus 0.01 for the rounding of u itself.
         const float n_walk = (float)(kDistRadius + 1) * __builtin_amdgcn_rcpf(fmaxf(dux, fmaxf(duy, duz)));
         const float mg = fmaf(n_walk * 0x1p-24f, fmaxf(fnx, fmaxf(fny, fnz)), 0.01f);
-        // Step margin: the walk below stops on the accumulated t; n additions drift by <= n * 2^-24 * t1,
-        // i.e. a fraction e = 2^-24 * t1 / dt of the walk length (x4 for the fma and rcp roundings).
-        const float e = fminf(0x1p-22f * t1 * __builtin_amdgcn_rcpf(dt), 1.0f);
-        const float sc = 1.0f - e, cst = -(e + 0.01f);
+        // (the walk counts its steps: no margin for a drifting loop variable; 2^-12 covers rcp and the fmas, 0.01 of a step on top)
+        constexpr float sc = 1.0f - 0x1p-12f, cst = -0.01f;
         skax = (sx >= 0.0f ? -idux : idux) * sc; skay = (sy >= 0.0f ? -iduy : iduy) * sc; skaz = (sz >= 0.0f ? -iduz : iduz) * sc;
         skbx = fmaf((sx >= 0.0f ? -mg : -1.0f - mg) * idux, sc, cst);
         skby = fmaf((sy >= 0.0f ? -mg : -1.0f - mg) * iduy, sc, cst);
@@ -146,18 +157,9 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
     const uint32_t doff = SKIP ? ((sx >= 0.0f ? 1u : 0u) | (sy >= 0.0f ? 2u : 0u) | (sz >= 0.0f ? 4u : 0u)) * V.dist_oct_stride : 0u;
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, SAFE ? 0u : (uint32_t)V.max_off + (1u << V.sh_x));
-    const float t1q = __builtin_canonicalizef(t1);  // known-quiet copy: keeps a per-trip canonicalise out of the skip branch
-    // WALK_FMA: steps per unit of t, rounded DOWN: the rounded increment of t is at most dt + h, h half an ulp of t1's binade (the largest t
-    // visits); 1 / (dt + h) >= (1 - h / dt) / dt, and 2^-12 covers rcp and the products.
-    float idt = 0.0f;
-    if (SKIP && WALK == WALK_FMA) {
-        const float inv = __builtin_amdgcn_rcpf(dt), h = __uint_as_float(__float_as_uint(t1) & 0x7f800000u) * 0x1p-24f;
-        idt = fmaxf(inv * fmaf(-h, inv, 1.0f) * (1.0f - 0x1p-12f), 0.0f);
-    }
 
-    // One exit test per trip: `t < t1` (:101) and the alpha early-out (:115-117) are folded into the
-    // loop condition; p and t are dead after the break, so advancing them unconditionally (:118)
-    // changes nothing observable.
+    // One exit test per trip: `t < t1` (:101, here: iterations left) and the alpha early-out (:115-117) are folded into the
+    // loop condition; p is dead after the break, so advancing it unconditionally (:118) changes nothing observable.
     uint32_t trip = 0;  // wave-uniform: the active lanes of a wave entered the loop together
     // AHEAD: where the ray stands, carried from trip to trip: lerp weights, cell index, and the cell's distance byte (possibly still in flight)
     float a_fx = 0.0f, a_fy = 0.0f, a_fz = 0.0f;
@@ -173,7 +175,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         a_d = V.dist[a_idx + doff];
     };
     if (AHEAD) locate(px, py, pz);
-    while (t < t1 && A < 0.95f && (!BOUNDED || trip < budget)) {
+    while (nleft != 0 && A < 0.95f && (!BOUNDED || trip < budget)) {
         if (BOUNDED) ++trip;
         if (COUNT) { n_look++; if (wave_leader()) w_outer++; }
         uint32_t *le = nullptr;
@@ -223,59 +225,46 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 const float rx = fmaf(fx, skax, fmaf(fd, idux, skbx));
                 const float ry = fmaf(fy, skay, fmaf(fd, iduy, skby));
                 const float rz = fmaf(fz, skaz, fmaf(fd, iduz, skbz));
-                // The walk advances the reference loop's own accumulators (p += s, t += dt: the same
-                // f32 additions in the same order) while t < tstop.  tstop <= t1, so every skipped
-                // iteration passed the reference's `t < t1` test on the very same t; and t_j < tstop
-                // means j < r.  The current sample (j = 0, its cell is empty) is always skipped.
+                // Samples j = 0 .. k - 1 are skipped, k = ceil(r) (j < r keeps a sample inside the empty range; the current sample, j = 0,
+                // sits in an empty cell: k >= 1), at most the trip's cap and at most the iterations the loop has left -- every skipped
+                // iteration is one the reference makes (it passes `t < t1` on the reference's own t: that is what `left` counts).
+                // The walk advances the reference's position, p += s, k times: the same f32 additions in the same order.
                 float rmin = fminf(fminf(rx, ry), rz);
                 if constexpr (WALK == WALK_FMA) {
-                    // Samples j = 0 .. m are skipped (the current sample's cell is empty: m >= 0): j < r keeps them inside the empty range.
-                    // t is kept EXACT, so that the ray takes the reference's number of iterations: two real additions give the increment
-                    // every further one repeats inside t_1's binade [B, 2B) (ties included), and m stays below the steps that remain
-                    // in that binade, (2B - t_1) / d, and in the ray: t_m < t1  <=  m <= ceil(x) for any x below (t1 - t_1) / d.  (`idt`
-                    // is 1 / dt rounded down far enough for both: d <= dt + half an ulp of t1's binade.)  A ray crosses two or three
-                    // binades of t: as many walks end early and resume next trip.  The three coordinates -- a dozen binades each on the
-                    // way from 0 to 1 -- take the increment of ONE real addition and are not cut: that is where the mode is a tolerance.
-                    const float t_1 = t + dt, x_1 = px + sx, y_1 = py + sy, z_1 = pz + sz;
-                    const float t_2 = t_1 + dt;
-                    const float in_binade = fmaf(__uint_as_float(__float_as_uint(t_1) & 0x7f800000u), 2.0f, -t_1) * idt;
-                    float m = fminf(__builtin_ceilf(rmin) - 1.0f, __builtin_ceilf((t1q - t_1) * idt));
-                    m = fmaxf(fminf(m, __builtin_floorf(in_binade)), 0.0f);
+                    // one real addition, the other k - 1 as one fma with that addition's rounded increment (tolerance: see WalkKind)
+                    const float x_1 = px + sx, y_1 = py + sy, z_1 = pz + sz;
+                    const int kneg = walk_steps_neg(rmin, nleft);  // -k
+                    const float m = (float)(-1 - kneg);
                     const float dx_q = x_1 - px, dy_q = y_1 - py, dz_q = z_1 - pz;
-                    t = fmaf(m, t_2 - t_1, t_1);
                     px = fmaf(m, dx_q, x_1); py = fmaf(m, dy_q, y_1); pz = fmaf(m, dz_q, z_1);
-                    if (COUNT) { n_iter += 1u + (uint32_t)m; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
+                    nleft -= kneg;
+                    if (COUNT) { n_iter += (uint32_t)(-kneg); if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                     if (AHEAD) locate(px, py, pz);
                     continue;
                 }
                 asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
-                float tstop = fmaf(rmin, dt, t);
-                asm("v_min_f32 %0, %1, %2" : "=v"(tstop) : "v"(tstop), "v"(t1q));    // (t1 is finite: no canonicalise per trip)
-                const float tstop2 = fmaf(-1.5f, dt, tstop);  // t < tstop2  =>  t + dt < tstop as well
-                const float tstop4 = fmaf(-3.5f, dt, tstop);  // t < tstop4  =>  t + 3 dt < tstop as well
+                const int c = walk_steps_neg(rmin, nleft);  // -k
+                nleft -= c;
+                if (COUNT) { n_iter += (uint32_t)(-c); if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                 px = px + sx; py = py + sy; pz = pz + sz;
-                t = t + dt;
-                if (COUNT) { n_iter++; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
-                while (t < tstop4) {  // four skipped iterations per trip of the walk
+                const uint32_t m = ~(uint32_t)c;  // k - 1: the steps after the first
+                // four skipped iterations per trip of the walk (the counter's decrement is its own test: v_sub_co)
+                for (uint32_t q = m >> 2; !__builtin_usub_overflow(q, 1u, &q);) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { px = px + sx; py = py + sy; pz = pz + sz; t = t + dt; }
-                    if (COUNT) { n_iter += 4; if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
+                    for (int j = 0; j < 4; j++) { px = px + sx; py = py + sy; pz = pz + sz; }
+                    if (COUNT) { if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                 }
-                if (t < tstop2) {
+                if (m & 2u) {
                     // (the empty asm keeps this an exec-masked region: if-converted, the two steps are computed for every lane and
-                    // then selected by FOUR v_cndmask through VCC in a row, ~16 issue cycles each -- profiles/r03_ubench_valu_issue_rate.txt --
+                    // then selected by v_cndmask through VCC in a row, ~16 issue cycles each -- profiles/r03_ubench_valu_issue_rate.txt --
                     // twice the cost of a whole four-step walk iteration)
-                    asm volatile("" : "+v"(t));
+                    asm volatile("" : "+v"(px));
                     px = px + sx; py = py + sy; pz = pz + sz;
-                    t = t + dt;
                     px = px + sx; py = py + sy; pz = pz + sz;
-                    t = t + dt;
-                    if (COUNT) { n_iter += 2; }
                 }
-                if (t < tstop) {
+                if (m & 1u) {
+                    asm volatile("" : "+v"(px));
                     px = px + sx; py = py + sy; pz = pz + sz;
-                    t = t + dt;
-                    if (COUNT) { n_iter++; }
                 }
                 if (AHEAD) locate(px, py, pz);
                 continue;
@@ -288,10 +277,10 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 cb = load_cell<VOL>(cells, coff);
             }
             if (AHEAD) {
-                // :118 and :101's increment now -- neither depends on the sample -- then the next position's distance byte is requested
+                // :118 and :101's increment (one iteration fewer left) now -- neither depends on the sample -- then the next position's distance byte is requested
                 // under this sample's arithmetic (fx, fy, fz keep THIS position's weights)
                 px = px + sx; py = py + sy; pz = pz + sz;
-                t = t + dt;
+                nleft += 1;
                 locate(px, py, pz);
             }
             xlerp_cell<VOL>(cb, fx, c00, c10, c01, c11);
@@ -353,7 +342,7 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                 if (COUNT) { n_iter++; n_samp++; if (wave_leader()) w_sample++; }
                 if (!AHEAD) {
                     px = px + sx; py = py + sy; pz = pz + sz;  // :118
-                    t = t + dt;
+                    nleft += 1;
                 }
                 continue;
             }
@@ -371,30 +360,31 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
         A = A + w;
         if (!AHEAD) {
             px = px + sx; py = py + sy; pz = pz + sz;  // :118
-            t = t + dt;
+            nleft += 1;
         }
     }
     if (AHEAD) asm volatile("" ::"v"(a_d));  // (the last request is consumed on the exit path too)
-    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
-    return t < t1 && A < 0.95f;
+    r.left = (uint32_t)(-nleft); r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    return nleft != 0 && A < 0.95f;
 }
 
 // The same loop for the fast path without skipping (every trip samples), software-pipelined: the
 // position is advanced first and the NEXT trip's cell is requested before this trip's sample is
 // evaluated, so the fetch latency overlaps the ~40 VALU instructions of a sample instead of adding
 // to them -- it is the lone heavy waves at the tail of a frame that set the frame time.  The f32
-// operations on t, p, A and the colour sums are those of march(), in the same order per variable.
+// operations on p, A and the colour sums are those of march(), in the same order per variable.
 // The request one step past the ray's end reads a real (clamped) table entry and is never used.
 // CELL_LUT: the tables hold cell indices (the skip kernels' copy) instead of byte offsets; `budget` bounds the trips
 // (0xffffffff: none) so that the skip kernels can run stretches of it between probing windows.
 template <int VOL, bool COUNT, bool CELL_LUT = false>
 __device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, Census &cs, const uint32_t *lut, uint32_t budget = 0xffffffffu) {
-    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
-    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    float px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    uint32_t left = r.left;
+    const float sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
     const uint32_t *luty = lut + (V.nx + 3), *lutz = lut + (V.nx + V.ny + 6);
     const __amdgpu_buffer_rsrc_t cells = cell_buffer(V.data, (uint32_t)V.max_off + (1u << V.sh_x));
-    if (!(t < t1 && A < 0.95f)) return false;
+    if (!(left != 0u && A < 0.95f)) return false;
     const uint32_t lsh = CELL_LUT ? V.sh_x : 0u;
     float fx, fy, fz;
     CellBits<VOL> c0, c1;  // two cell buffers, used alternately (no register copies between trips)
@@ -423,9 +413,9 @@ __device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, C
         const float w = (1.0f - A) * a;  // :112-114
         Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
         A = A + w;
-        t = t + dt;
+        left -= 1u;  // :101
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
-        return t < t1 && A < 0.95f;
+        return left != 0u && A < 0.95f;
     };
     bool alive = true;
     for (;;) {
@@ -437,7 +427,7 @@ __device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, C
     // The last requests are consumed here, on the exit path too: with a use on both sides of the exit
     // branch the compiler cannot sink a request behind it (which would undo the pipelining).
     asm volatile("" ::"v"(c0.v), "v"(c1.v));
-    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    r.left = left; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
     return alive;
 }
 
@@ -447,11 +437,12 @@ __device__ __forceinline__ bool march_stream(const VolumeDesc &V, RayState &r, C
 template <int VOL, bool COUNT>
 __device__ __forceinline__ void march_b9_stream(const VolumeDesc &V, RayState &r, Census &cs) {
     static_assert(VOL == VOL_B9U8 || VOL == VOL_B9F16, "9^3 brick layouts");
-    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
-    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    float px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    uint32_t left = r.left;
+    const float sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
     const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
-    if (!(t < t1 && A < 0.95f)) return;
+    if (!(left != 0u && A < 0.95f)) return;
     typedef uint16_t u16_unaligned __attribute__((aligned(1)));
     typedef uint32_t u32_unaligned __attribute__((aligned(2)));
     struct Taps { uint32_t p00, p10, p01, p11; };  // x pairs at (y, z) = (0,0) (1,0) (0,1) (1,1)
@@ -505,27 +496,28 @@ __device__ __forceinline__ void march_b9_stream(const VolumeDesc &V, RayState &r
         const float w = (1.0f - A) * a;  // :112-114
         Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
         A = A + w;
-        t = t + dt;
+        left -= 1u;  // :101
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
-        return t < t1 && A < 0.95f;
+        return left != 0u && A < 0.95f;
     };
     for (;;) {
         if (!trip(c0, c1)) break;
         if (!trip(c1, c0)) break;
     }
     asm volatile("" ::"v"(c0.p00), "v"(c0.p10), "v"(c0.p01), "v"(c0.p11), "v"(c1.p00), "v"(c1.p10), "v"(c1.p01), "v"(c1.p11));
-    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    r.left = left; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
 // The quad layouts: one load per sample (two consecutive elements), software-pipelined like the others.
 template <int VOL, bool COUNT>
 __device__ __forceinline__ void march_quads_stream(const VolumeDesc &V, RayState &r, Census &cs) {
     static_assert(VOL == VOL_Q8 || VOL == VOL_QF16, "quad layouts");
-    float t = r.t, px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
-    const float t1 = r.t1, dt = r.dt, sx = r.sx, sy = r.sy, sz = r.sz;
+    float px = r.px, py = r.py, pz = r.pz, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    uint32_t left = r.left;
+    const float sx = r.sx, sy = r.sy, sz = r.sz;
     const float fnx = (float)V.nx, fny = (float)V.ny, fnz = (float)V.nz;
     const int mx = (int)V.nx - 1, my = (int)V.ny - 1, mz = (int)V.nz - 1;
-    if (!(t < t1 && A < 0.95f)) return;
+    if (!(left != 0u && A < 0.95f)) return;
     typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // elements are 4 / 8 bytes: the pair is under-aligned
     typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     struct Taps { uint32_t a, b, c, d; };  // u8: a = element(x), b = element(x+1); f16: (a, b) = element(x), (c, d) = element(x+1)
@@ -578,16 +570,16 @@ __device__ __forceinline__ void march_quads_stream(const VolumeDesc &V, RayState
         const float w = (1.0f - A) * a;  // :112-114
         Gr = fmaf(w, cr, Gr); Gg = fmaf(w, cg, Gg); Gb = fmaf(w, cb, Gb);
         A = A + w;
-        t = t + dt;
+        left -= 1u;  // :101
         fx = __builtin_amdgcn_fractf(ux); fy = __builtin_amdgcn_fractf(uy); fz = __builtin_amdgcn_fractf(uz);
-        return t < t1 && A < 0.95f;
+        return left != 0u && A < 0.95f;
     };
     for (;;) {
         if (!trip(c0, c1)) break;
         if (!trip(c1, c0)) break;
     }
     asm volatile("" ::"v"(c0.a), "v"(c0.b), "v"(c0.c), "v"(c0.d), "v"(c1.a), "v"(c1.b), "v"(c1.c), "v"(c1.d));
-    r.t = t; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    r.left = left; r.px = px; r.py = py; r.pz = pz; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
 // Whole frames in a batched launch: the march covers the active tiles; the tiles behind a frame's active positions hold
@@ -683,12 +675,12 @@ __global__ __launch_bounds__(64) void raymarch_naive_kernel(const LaunchDesc L, 
         float px = eye[0] + t0 * dir[0], py = eye[1] + t0 * dir[1], pz = eye[2] + t0 * dir[2];  // :100
         const float sx = dir[0] * dt, sy = dir[1] * dt, sz = dir[2] * dt;  // :118
         RayState r;
-        r.t = t0; r.t1 = t1; r.dt = dt;
+        r.left = min(count_trips(t0, t1, dt), 0x7fffffffu);  // :101
         r.px = px; r.py = py; r.pz = pz; r.sx = sx; r.sy = sy; r.sz = sz;
         r.A = 0.0f; r.Gr = 0.0f; r.Gg = 0.0f; r.Gb = 0.0f;  // colour sums: G = sum w*cos(phase); C = A/2 + G/2 (sum w == A)
         r.out = (uint32_t)pm.out_index;
         // (not in the skip kernels: a ray's nominal length says little about its work there -- C2 at 64 orbit frames per launch 0.06509 -> 0.06467 ms without)
-        if (!SKIP && (L.flags & LF_WAVE_PRIORITY)) set_wave_priority(true, t0, t1, dt, fmaxf(fnx, fmaxf(fny, fnz)) / L.dt_scale);
+        if (!SKIP && (L.flags & LF_WAVE_PRIORITY)) set_wave_priority(true, r.left, fmaxf(fnx, fmaxf(fny, fnz)) / L.dt_scale);
         if constexpr (USE_LUT && !SKIP) march_stream<VOL, COUNT>(V, r, cs, cell_lut);
         else if constexpr (SKIP) {
             if (L.flags & LF_ADAPTIVE_PROBING) {

@@ -219,16 +219,17 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     constexpr int BPV = U8 ? 1 : 2, VSH = U8 ? 4 : 3;
     extern __shared__ unsigned char stage_win[];
     const uint32_t win_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage_win;  // LDS byte address of the window
-    float t = r.t, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    float A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    uint32_t left = r.left;  // iterations of :101 not made yet (RayState)
     float p[3] = {r.px, r.py, r.pz};
-    const float s[3] = {r.sx, r.sy, r.sz}, t1 = r.t1, dt = r.dt;
+    const float s[3] = {r.sx, r.sy, r.sz};
     const float fn[3] = {(float)V.nx, (float)V.ny, (float)V.nz};
     const unsigned char *const base = D.copy[PERM];
     const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM], cap = D.cap_bytes;
     const int T0 = (int)D.slab_cells;
     const int nvm1[3] = {(int)D.nv[0] - 1, (int)D.nv[1] - 1, (int)D.nv[2] - 1};
 
-    alive = alive && (t < t1 && A < 0.95f);
+    alive = alive && (left != 0u && A < 0.95f);
     const float duS = s[S] * fn[S];  // cells per step along S
     const bool dir_up = __popcll(__ballot(alive && duS > 0.0f)) >= __popcll(__ballot(alive && duS < 0.0f));  // wave-uniform
     const bool fit = alive && (dir_up ? duS >= 0.2f : duS <= -0.2f);
@@ -240,7 +241,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
     bool have_sig = false;
     const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
     for (;;) {
-        const bool live = fit && (t < t1 && A < 0.95f);
+        const bool live = fit && (left != 0u && A < 0.95f);
         if (__ballot(live) == 0ull) break;  // wave-uniform
         const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
         const int iS = cvt_floor_i32(uS);
@@ -331,7 +332,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
                     const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
                     // one exit test per step: the ray ended (:101, :115-117) or left the slab (or has not reached it)
-                    if (!((int)(t < t1) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
+                    if (!((int)(left != 0u) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
                     const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
                     const int a0 = mad_i24(i[S], sliceB, mad_i24(i[M], rowB, i[F] * BPV + cbase));  // |operands| < 2^23
                     uint32_t lo[4], hi[4];
@@ -340,7 +341,7 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
                     composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                     if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
                     p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
-                    t = t + dt;
+                    left -= 1u;  // :101
                 }
             }
         } else if (live && iS == sig) {
@@ -349,23 +350,23 @@ __device__ __forceinline__ void march_staged_perm(const VolumeDesc &V, const Sta
             composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
             if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
             p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
-            t = t + dt;
+            left -= 1u;
         }
         if (COUNT && wave_leader()) { cs.w_outer++; if (!fits) cs.w_inner++; cs.w_sample += (uint32_t)T; }
     }
     // rays that do not travel with the wave along S
     if (__ballot(alive && !fit) != 0ull) {
         if (alive && !fit) {
-            while (t < t1 && A < 0.95f) {
+            while (left != 0u && A < 0.95f) {
                 const float v = sample_global<VOL, PERM>(D, p, fn);
                 composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                 if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
                 p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
-                t = t + dt;
+                left -= 1u;
             }
         }
     }
-    r.t = t; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    r.left = left; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
 // ---- the same march with ONE window for the four waves of a 256-thread group (2 x 2 neighbouring 8x8 blocks) ------------------
@@ -389,16 +390,17 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
     extern __shared__ unsigned char stage_win[];
     int *const ex = reinterpret_cast<int *>(stage_win);  // the group's exchange block (kGroupExchBytes), then the window
     const uint32_t win_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)stage_win + kGroupExchBytes;  // LDS byte address of the window
-    float t = r.t, A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    float A = r.A, Gr = r.Gr, Gg = r.Gg, Gb = r.Gb;
+    uint32_t left = r.left;  // iterations of :101 not made yet (RayState)
     float p[3] = {r.px, r.py, r.pz};
-    const float s[3] = {r.sx, r.sy, r.sz}, t1 = r.t1, dt = r.dt;
+    const float s[3] = {r.sx, r.sy, r.sz};
     const float fn[3] = {(float)V.nx, (float)V.ny, (float)V.nz};
     const unsigned char *const base = D.copy[PERM];
     const uint32_t npf = D.npf[PERM], nbm = D.nbm[PERM], cap = D.cap_bytes;
     const int T0 = (int)D.slab_cells;
     const int nvm1[3] = {(int)D.nv[0] - 1, (int)D.nv[1] - 1, (int)D.nv[2] - 1};
 
-    alive = alive && (t < t1 && A < 0.95f);
+    alive = alive && (left != 0u && A < 0.95f);
     const float duS = s[S] * fn[S];  // cells per step along S
     // (dir_up: the GROUP's direction of travel along S, decided by the kernel over all four waves)
     const bool fit = alive && (dir_up ? duS >= 0.2f : duS <= -0.2f);
@@ -411,7 +413,7 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
     const uint64_t layerB = ((uint64_t)npf * (uint64_t)nbm) << 10;  // bytes of one layer of bricks along S
     uint32_t par = 0;  // the exchange accumulators alternate between two sets (see group_exchange)
     for (;;) {
-        const bool live = fit && (t < t1 && A < 0.95f);
+        const bool live = fit && (left != 0u && A < 0.95f);
         const int any_mine = __ballot(live) != 0ull ? 1 : 0;
         const float uS = fmaf(p[S], fn[S], -0.5f), uM = fmaf(p[M], fn[M], -0.5f), uF = fmaf(p[F], fn[F], -0.5f);
         const int iS = cvt_floor_i32(uS);
@@ -528,7 +530,7 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
                     const float ux = fmaf(p[0], fn[0], -0.5f), uy = fmaf(p[1], fn[1], -0.5f), uz = fmaf(p[2], fn[2], -0.5f);
                     const int i[3] = {cvt_floor_i32(ux), cvt_floor_i32(uy), cvt_floor_i32(uz)};
                     // one exit test per step: the ray ended (:101, :115-117) or left the slab (or has not reached it)
-                    if (!((int)(t < t1) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
+                    if (!((int)(left != 0u) & (int)(A < 0.95f) & (int)((uint32_t)(i[S] - clo) < (uint32_t)T))) break;
                     const float fx = __builtin_amdgcn_fractf(ux), fy = __builtin_amdgcn_fractf(uy), fz = __builtin_amdgcn_fractf(uz);
                     const int a0 = mad_i24(i[S], sliceB, mad_i24(i[M], rowB, i[F] * BPV + cbase));  // |operands| < 2^23
                     uint32_t lo[4], hi[4];
@@ -537,7 +539,7 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
                     composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                     if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; }
                     p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];  // :118
-                    t = t + dt;
+                    left -= 1u;  // :101
                 }
             }
         } else {
@@ -548,7 +550,7 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
             composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
             if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
             p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
-            t = t + dt;
+            left -= 1u;
           }
         }
         if (COUNT && wave_leader()) { cs.w_outer++; if (!fits) cs.w_inner++; cs.w_sample += (uint32_t)T; }
@@ -557,16 +559,16 @@ __device__ __forceinline__ void march_staged_group_perm(const VolumeDesc &V, con
     // rays that do not travel with the wave along S
     if (__ballot(alive && !fit) != 0ull) {
         if (alive && !fit) {
-            while (t < t1 && A < 0.95f) {
+            while (left != 0u && A < 0.95f) {
                 const float v = sample_global<VOL, PERM>(D, p, fn);
                 composite_step<U8 ? 2 : 0>(v, A, Gr, Gg, Gb);
                 if (COUNT) { cs.n_look++; cs.n_iter++; cs.n_samp++; cs.n_fb++; }
                 p[0] = p[0] + s[0]; p[1] = p[1] + s[1]; p[2] = p[2] + s[2];
-                t = t + dt;
+                left -= 1u;
             }
         }
     }
-    r.t = t; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
+    r.left = left; r.px = p[0]; r.py = p[1]; r.pz = p[2]; r.A = A; r.Gr = Gr; r.Gg = Gg; r.Gb = Gb;
 }
 
 // fs_main (raycast_naive.wgsl:83-125) on the staged layout.  Same ray set-up, output and counters as
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
     }
     RayState r;
-    r.t = 0.0f; r.t1 = 0.0f; r.dt = 1.0f; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
+    r.left = 0u; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
     r.A = 0.0f; r.Gr = r.Gg = r.Gb = 0.0f; r.out = 0;
     bool hit = false;
     if (pm.valid) {
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             float dty = 1.0f / (fny * fabsf(dir[1]));
             float dtz = 1.0f / (fnz * fabsf(dir[2]));
             const float dt = L.dt_scale * fminf(dtx, fminf(dty, dtz));  // :97-99
-            r.t = t0; r.t1 = t1; r.dt = dt;
+            r.left = min(count_trips(t0, t1, dt), 0x7fffffffu);  // :101
             r.px = eye[0] + t0 * dir[0]; r.py = eye[1] + t0 * dir[1]; r.pz = eye[2] + t0 * dir[2];  // :100
             r.sx = dir[0] * dt; r.sy = dir[1] * dt; r.sz = dir[2] * dt;  // :118
             hit = true;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int c0 = __popcll(__ballot(hit && mj == 0)), c1 = __popcll(__ballot(hit && mj == 1)), c2 = __popcll(__ballot(hit && mj == 2));
     Census cs;
     if (c0 + c1 + c2 != 0) {  // wave-uniform
-        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
+        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.left, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
         if (copy == 0u) march_staged_perm<VOL, 0, COUNT>(V, D, r, hit, cs, lane);
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int bx0 = pm.x - (int)(lane & 7u), by0 = pm.y - (int)(lane >> 3);
     const bool culled = bx0 + 8 <= fv.cull_x0 || bx0 >= fv.cull_x1 || by0 + 8 <= fv.cull_y0 || by0 >= fv.cull_y1;  // wave-uniform: this wave holds only misses
     RayState r;
-    r.t = 0.0f; r.t1 = 0.0f; r.dt = 1.0f; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
+    r.left = 0u; r.px = r.py = r.pz = 0.0f; r.sx = r.sy = r.sz = 0.0f;
     r.A = 0.0f; r.Gr = r.Gg = r.Gb = 0.0f; r.out = 0;
     bool hit = false;
     if (pm.valid && !culled) {
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             float dty = 1.0f / (fny * fabsf(dir[1]));
             float dtz = 1.0f / (fnz * fabsf(dir[2]));
             const float dt = L.dt_scale * fminf(dtx, fminf(dty, dtz));  // :97-99
-            r.t = t0; r.t1 = t1; r.dt = dt;
+            r.left = min(count_trips(t0, t1, dt), 0x7fffffffu);  // :101
             r.px = eye[0] + t0 * dir[0]; r.py = eye[1] + t0 * dir[1]; r.pz = eye[2] + t0 * dir[2];  // :100
             r.sx = dir[0] * dt; r.sy = dir[1] * dt; r.sz = dir[2] * dt;  // :118
             hit = true;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float cs3[3] = {r.sx * (float)V.nx, r.sy * (float)V.ny, r.sz * (float)V.nz};  // cells per step, signed
         const float ax = fabsf(cs3[0]), ay = fabsf(cs3[1]), az = fabsf(cs3[2]);
         const int mj = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-        const bool alive0 = hit && r.t < r.t1;
+        const bool alive0 = hit && r.left != 0u;
         int cnt[9];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int c0 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 0]), c1 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 1]), c2 = __builtin_amdgcn_readfirstlane(ex[kGroupAccI + 2]);
     Census cs;
     if (c0 + c1 + c2 != 0) {  // group-uniform
-        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.t, r.t1, r.dt, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
+        if (L.flags & LF_WAVE_PRIORITY) set_wave_priority(hit, r.left, fmaxf((float)V.nx, fmaxf((float)V.ny, (float)V.nz)) / L.dt_scale);
         const int major = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
         const uint32_t copy = D.copy_of_major[major];
         // (the S axis of copy k is axis k: the direction of travel is counted on that axis)
