@@ -214,7 +214,8 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
             // (One compare serves the branch and the wave-level test; the cap is a scalar.)
             // (one compare serves the branch and the wave-level test; the cap is chosen on the scalar unit, as bits)
             const unsigned long long samplers = SKIP ? __ballot(d == 0) : 0ull;
-            const uint32_t cap_now = samplers != 0ull ? __builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap)) : __builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap_all));
+            uint32_t cap_now;  // (s_cmp + s_cselect: written as a ternary the compiler builds two branches and five moves around it; C2 batches -0.6 %)
+            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(cap_now) : "s"(samplers), "s"(__builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap))), "s"(__builtin_amdgcn_readfirstlane(__float_as_uint(walk_cap_all))) : "scc");
             if (SKIP && d != 0) {
                 if (BOUNDED) cs.skips++;
                 // Every cell within Chebyshev distance d-1 of this one is empty.  Sample j sits at
@@ -243,16 +244,23 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     continue;
                 }
                 asm("v_min_f32 %0, %1, %2" : "=v"(rmin) : "s"(cap_now), "v"(rmin));  // (a known-quiet scalar: no canonicalise)
-                const int c = walk_steps_neg(rmin, nleft);  // -k
+                // m = k - 1: the steps after the first.  Single-frame launches (AHEAD) round it down to even -- the odd step is left to the next
+                // trip's probe (any stop is exact) and the walk loses a branch: the lone chains of a single frame pay per instruction
+                // (C2 single frame -3.7 %; batches +2 %: they keep the odd step)
+                const uint32_t m = ~(uint32_t)walk_steps_neg(rmin, nleft) & (AHEAD ? ~1u : ~0u);
+                const int c = (int)~m;  // -k
                 nleft -= c;
                 if (COUNT) { n_iter += (uint32_t)(-c); if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
                 px = px + sx; py = py + sy; pz = pz + sz;
-                const uint32_t m = ~(uint32_t)c;  // k - 1: the steps after the first
                 // four skipped iterations per trip of the walk (the counter's decrement is its own test: v_sub_co)
                 for (uint32_t q = m >> 2; !__builtin_usub_overflow(q, 1u, &q);) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) { px = px + sx; py = py + sy; pz = pz + sz; }
                     if (COUNT) { if (wave_leader()) { w_inner++; if (le) atomicAdd(le, 1u << 21); } }
+                }
+                if (!AHEAD && (m & 1u)) {
+                    asm volatile("" : "+v"(px));
+                    px = px + sx; py = py + sy; pz = pz + sz;
                 }
                 if (m & 2u) {
                     // (the empty asm keeps this an exec-masked region: if-converted, the two steps are computed for every lane and
@@ -260,10 +268,6 @@ __device__ __forceinline__ bool march(const VolumeDesc &V, RayState &r, const ui
                     // twice the cost of a whole four-step walk iteration)
                     asm volatile("" : "+v"(px));
                     px = px + sx; py = py + sy; pz = pz + sz;
-                    px = px + sx; py = py + sy; pz = pz + sz;
-                }
-                if (m & 1u) {
-                    asm volatile("" : "+v"(px));
                     px = px + sx; py = py + sy; pz = pz + sz;
                 }
                 if (AHEAD) locate(px, py, pz);
