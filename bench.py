@@ -256,6 +256,62 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ctx.close()
 
 
+def c5_at_n(V, torch, dist, BatchTileRenderer, rank, world, local_rank, rehearsal, transport, frames=16, batch=4):
+    """BASELINE's own 8-GPU configuration (C5: 2048^3 u8, 3840x2160) through the N > 1 driver -- the same partition, gather and un-tile as
+    the headline's C2 frames -- with a fixed root and with a rotating one.  EVERY rank calls this (it is full of collectives); the ranks
+    agree on each set-up's outcome before they enter a timed window, and an exception inside a window is not caught (it ends the job
+    through the launcher instead of leaving the others parked in a barrier).  Returns the `extras.c5_at_n` object on rank 0."""
+    cfg = CONFIGS["c5"]
+    W, H, ts = cfg["W"], cfg["H"], tile_of(cfg)
+    stream = torch.cuda.Stream()
+    res = {"workload": cfg["name"], "frames_per_launch": batch, "timed_frames": frames, "tile": ts}
+    with torch.cuda.stream(stream):
+        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
+        ctx = V.Context(W, H, cam, device=local_rank, backbuffer=(W, H), out_format=V.OUT_RGBA16F, stream=stream.cuda_stream)
+        try:
+            res["volume_setup_s"] = make_volume(V, ctx, cfg, V.LAYOUT_AUTO)
+            ctx.update()
+            s_ref, s_samp = count_steps(ctx, V, 0)
+            res["s_ref_per_frame"], res["s_sampled_per_frame"] = s_ref, s_samp
+            pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE)
+            cams = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
+            for name, root in (("fixed_root", 0), ("rotating_root", "rotate")):
+                btr, why = None, None
+                try:
+                    btr = BatchTileRenderer(ctx, pipe, tile_size=ts, batch=batch, root=root, transport=transport, via_host=rehearsal)
+                except Exception as e:  # noqa: BLE001
+                    why = repr(e)
+                okt = torch.tensor([0 if why else 1], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if not int(okt.item()):
+                    res[name] = {"error": why or "set-up failed on another rank"}
+                    if btr is not None:
+                        btr.close()
+                    continue
+
+                def window(k):
+                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for j in range(k):
+                        btr.submit(cams[j % batch])
+                    btr.flush()
+                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    return float(tt.item())
+
+                window(2 * batch)
+                el = sorted(window(frames) for _ in range(3))[1]
+                res[name] = {"ms_per_frame": el / frames * 1e3, "value": s_ref * frames / el / 1e6, "unit": "Mray-steps/s", "root_skip": btr.root_skip,
+                             "frac": (s_samp * cfg["b_step"] + W * H * B_RAY) * frames / el / 1e9 / (HBM_PEAK_GBS * world)}
+                btr.close()
+        finally:
+            ctx.close()
+    res["note"] = ("C5 frames through the N > 1 driver (64 x 64-pixel tiles dealt heaviest-first, one launch + one gather + one un-tile per batch), median of "
+                   "three windows, max over ranks; the volume is replicated on every GPU (26 GB of 288)")
+    return res if rank == 0 else None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` typed like the N = 1 line: start the N ranks as a CHILD torch.distributed.run (never an exec,
     and before anything in this process has touched the GPU), relay its output, leave with its exit code."""
@@ -898,6 +954,11 @@ def main():
                     out["extras"][name] = big_config_extra(V, torch, local_rank, key)
                 except Exception as e:
                     out["extras"][name] = {"error": str(e)}
+    # N > 1: BASELINE's 8-GPU configuration through the same driver, after the C2 context is gone.  Every rank takes part.
+    if use_dist and world > 1 and args.config == "c2" and not args.no_extras and os.environ.get("VK_BENCH_C5_AT_N", "1") != "0":
+        r5 = c5_at_n(V, torch, dist, BatchTileRenderer, rank, world, local_rank, rehearsal, transport)
+        if rank == 0:
+            out.setdefault("extras", {})["c5_at_n"] = r5
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

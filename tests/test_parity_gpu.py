@@ -1536,6 +1536,44 @@ def test_bench_multi_rank_flow_rehearsal(V, O, how):
     assert d["rotating_root"]["value"] > 0 and d["config"]["wire"]["format"] == "rgb" and d["config"]["wire"]["bytes_per_pixel"] == 6
 
 
+@pytest.mark.parametrize("what", ["config_c5", "c5_at_n"])
+def test_bench_c5_two_rank_rehearsal(V, O, what):
+    """BASELINE's 8-GPU configuration (C5: 2048^3 u8, 3840x2160, replicated volume, framebuffer tiles over the ranks) through bench.py's N > 1
+    flow with two ranks on this one GPU (2 x 26 GB of bricks fit): the JSON contract of
+      config_c5: `bench.py --gpus 2 --config c5` -- C5 as the line's own workload;
+      c5_at_n:   `bench.py --gpus 2` -- the C2 line the driver's scaling run produces, with C5 through the same partition + gather + un-tile in
+                 extras.c5_at_n (fixed root and rotating root), so that the first real 8-GPU run yields BASELINE's own 8-GPU configuration too.
+    A test of the flow, not a measurement.  Generalises the reference's tile loop, examples/xor/main.rs:77-95,235-254."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    cmd += ["--config", "c5", "--no-extras"] if what == "config_c5" else ["--no-rotate"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VK_BENCH_REHEARSAL")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mray-steps/s" and d["value"] > 0 and "rehearsal" in d
+    assert d["timed_frames"] >= 100 and d["timed_frames"] % 4 == 0 and d["timed_region_s"] > 0
+    assert abs(d["timed_region_s"] / d["timed_frames"] * 1e3 / d["ms_per_step"] - 1.0) < 1e-9
+    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    if what == "config_c5":
+        assert d["config"]["workload"].startswith("C5") and d["frames_per_launch"] * d["launches_per_region"] >= d["timed_frames"]
+        # the fog never reaches the early-out: every ray takes its nominal iterations, ~6.2e9 of them per frame (SURVEY 8d)
+        assert 5.5e9 < d["config"]["s_ref_config_camera"] < 6.8e9 and d["config"]["s_sampled_config_camera"] == d["config"]["s_ref_config_camera"]
+        assert d["rotating_root"]["value"] > 0
+    else:
+        assert d["config"]["s_ref_config_camera"] == 148393048
+        c5 = d["extras"]["c5_at_n"]
+        assert c5["workload"].startswith("C5") and 5.5e9 < c5["s_ref_per_frame"] < 6.8e9
+        for mode in ("fixed_root", "rotating_root"):
+            assert c5[mode]["value"] > 0 and c5[mode]["ms_per_frame"] > 0, c5[mode]
+
+
 def test_multi_peer_branches_under_fake_rccl(V, O):
     """The branches that only run with more than one peer -- vk_group_render's n > 1 path and vk_gather_tiles' root branch --
     executed on this one GPU through a single-process stand-in for RCCL (tests/fake_rccl.cpp, bound via VK_RCCL_LIB): n = 2, 3, 8
