@@ -221,7 +221,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         fr = torch.empty((nb, H, W, 4), dtype=torch.float16, device="cuda")
         # consecutive frames of an orbit (yaw step 2 pi / 1024), not one camera repeated: identical frames in one launch
         # share their brick fetches in L2 / Infinity Cache and run up to 20 % faster than any real frame stream
-        # (tools/big_batch_orbit.py); unrelated views in one launch gain nothing over single launches
+        # (docs/archive/tools/big_batch_orbit.py); unrelated views in one launch gain nothing over single launches
         blobs = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(nb)]
         ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, blobs, fr.data_ptr(), tile_size=tile_of(cfg)), 3, warm=1) / nb
         del fr
@@ -400,7 +400,7 @@ def main():
     batch = args.batch or {"c2": 128, "c4": 4, "c5": 4}[args.config]  # (C2 per frame at 32 / 64 / 128 / 256 frames per launch: 0.0677 / 0.0659 / 0.0644 / 0.0645 ms)
     if not args.batch and args.config == "c2" and world > 1:
         # a rank's launch covers 1 / N of every frame: more frames per launch keep it from paying the launch's tail N times as
-        # often (tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at 16 / 32 / 64 / 128 frames per launch)
+        # often (docs/archive/tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at 16 / 32 / 64 / 128 frames per launch)
         batch = min(256, max(128, 32 * world))
     batch = max(1, batch)
     # ONE contiguous timed window (>= 100 timed frames): M = the multiple of K that covers max(100, four launches)
@@ -460,7 +460,7 @@ def main():
         # 1024: src/camera.rs turns the camera on input), every frame its own camera.  A launch that repeats ONE camera skips
         # the per-camera host work (tile order, cull rectangle, descriptors) and shares every fetch between its frames in
         # L2 / Infinity Cache -- up to 20 % faster than any real frame stream on the beyond-cache configs
-        # (tools/big_batch_orbit.py), 3 % on C2; it is reported beside the headline as `still_camera`.
+        # (docs/archive/tools/big_batch_orbit.py), 3 % on C2; it is reported beside the headline as `still_camera`.
         cam_list = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
         tot_ref = tot_samp = 0
         for cb in cam_list:

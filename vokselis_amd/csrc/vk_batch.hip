@@ -75,7 +75,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     std::vector<uint32_t> &order = ctx->batch_order, &pos = ctx->batch_pos;
     // Estimate rays per tile: the 3 x 3 grid of the single-frame launches, or just the tile's centre ray when the grid
     // spans >= 4 frames -- position-major over many frames the launch time no longer depends on the finer estimate
-    // (tools/order_rays.py) and the host's share drops from 40 to 10 us per camera, which is what an orbiting camera
+    // (docs/archive/tools/order_rays.py) and the host's share drops from 40 to 10 us per camera, which is what an orbiting camera
     // at N = 8 (13.6 us of march per frame and rank) needs.
     const int G = n_frames >= 4 ? (int)ctx->order_rays_batch : (int)ctx->order_rays;
     const uint32_t kk[8] = {(uint32_t)geo_mode, ts, ctx->width, ctx->height, ctx->nx, ctx->ny, ctx->nz, (uint32_t)G};

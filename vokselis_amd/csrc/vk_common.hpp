@@ -122,7 +122,7 @@ enum LaunchFlag : uint32_t {
     LF_WAVE_PRIORITY = 16u,       // s_setprio by the length of the wave's longest ray (set_wave_priority)
     LF_FRAME_RUNS = 32u,          // batched launches: every XCD marches a run of consecutive frames of a tile position
     LF_PROBE_AHEAD = 128u,        // skip kernels, fast path: the next position's distance byte is requested under this trip's sample (vk_march.hpp: AHEAD)
-    LF_TRIP_LOG = 64u,            // COUNT builds: `trace` holds per-trip logs of trip_log_cap entries per wave (tools/repack_census.py)
+    LF_TRIP_LOG = 64u,            // COUNT builds: `trace` holds per-trip logs of trip_log_cap entries per wave (docs/archive/tools/repack_census.py)
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------

@@ -237,8 +237,8 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     if (n == "stage_cap_bytes") ctx->stage_cap_bytes = (uint32_t)value;          // LDS window of the staged march (next render)
     else if (n == "stage_slab_cells") ctx->stage_slab_cells = (uint32_t)value;   // cells per slab along the major axis (next render)
     else if (n == "trip_log_cap") { if (value < 0 || value > 4096 || ((uint32_t)value & 7u)) return fail(ctx, VK_ERR_INVALID, "trip_log_cap: a multiple of 8 up to 4096"); ctx->trip_log_cap = (uint32_t)value; }
-    else if (n == "stage_group") ctx->stage_group = (uint32_t)value;             // staged march: windows shared by the four waves of a group (tools/staged_group.py)
-    else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (tools/frame_runs.py)
+    else if (n == "stage_group") ctx->stage_group = (uint32_t)value;             // staged march: windows shared by the four waves of a group (docs/archive/tools/staged_group.py)
+    else if (n == "frame_runs") ctx->frame_runs = (uint32_t)value;               // batched launches: runs of consecutive frames per XCD (docs/archive/tools/frame_runs.py)
     else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
     else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;

@@ -37,7 +37,7 @@ struct vk_ctx {
     uint32_t stage_cap_bytes = 0, stage_slab_cells = 0, stage_copies_mask = 7;  // tunables (vk_debug_set_param)
     uint32_t stage_group = 2;    // staged march: one LDS window per 256-thread group of four waves (vk_staged.hpp: raymarch_staged_group_kernel): 0 never, 1 always, 2 where it pays (launch_staged)
     uint32_t frame_runs = 1;     // batched launches: every XCD marches a run of consecutive frames of a tile position (0: frames x, x + 8, ... as in round 2)
-    uint32_t stage_grow_every = 0;  // slab search: try one cell above the last fit every n-th round (0: 4 for u8, 1 for f16; tools/staged_grow.py)
+    uint32_t stage_grow_every = 0;  // slab search: try one cell above the last fit every n-th round (0: 4 for u8, 1 for f16; docs/archive/tools/staged_grow.py)
     uint32_t stage_row_pad = 2;  // odd LDS row pitch of the staged window: 0 never, 1 always, 2 (default) with group windows on u8 volumes (launch_staged)
     uint8_t *dist = nullptr;
     uint32_t *lut = nullptr;  // per-axis cell-index tables (cell units | byte offsets), cell layouts only
@@ -68,7 +68,7 @@ struct vk_ctx {
     size_t trace_blocks = 0;
     int wire = VK_WIRE_RGBA;     // compact tiles of a partition: whole pixels, or colour only (vk_partition_wire)
     bool want_trace = false;
-    uint32_t trip_log_cap = 0;   // > 0: the trace buffer holds per-trip logs of that many u32 entries per wave instead of stamps (tools/repack_census.py)
+    uint32_t trip_log_cap = 0;   // > 0: the trace buffer holds per-trip logs of that many u32 entries per wave instead of stamps (docs/archive/tools/repack_census.py)
     // The device copies of (order, order_pos) live in a ring of kOrderRing slots fed from pinned staging: a new
     // camera takes the next slot with one stream-ordered copy -- no host or device synchronisation -- while
     // launches still in flight (other streams: frames in flight) keep reading the slots they were given.
@@ -102,12 +102,12 @@ struct vk_ctx {
     std::vector<uint32_t> batch_order, batch_pos;
     uint32_t batch_n_active = 0;
     // Skip kernels: steps a walk may take in a trip in which other lanes sample / in which every lane walks (0: no cap).
-    // tools/walk_cap_sweep.py: 8 / 12 -- C2 0.0806 -> 0.0728 ms per frame in batches, 0.1625 -> 0.1555 single; a fog with
+    // docs/archive/tools/walk_cap_sweep.py: 8 / 12 -- C2 0.0806 -> 0.0728 ms per frame in batches, 0.1625 -> 0.1555 single; a fog with
     // 80 % of its 16^3 blocks knocked out 0.161 -> 0.135.  Multiples of the walk loop's four steps do best.
     uint32_t walk_cap = 8, walk_cap_all = 12;
     uint32_t render_tile = 0;    // vk_render: tile size of the launch order (0: 64, 32 for the staged march)
     uint32_t pair_ring = 0;      // compute twin: request buffers in the SHADE ring (4, 6; 42: 4 buffers, two revolutions per loop iteration; 0: by launch shape)
-    uint32_t pair_walk_min = 4;  // compute twin: shortest run of empty records worth a walk (a walk restarts the request ring; tools/compute_mode.py)
+    uint32_t pair_walk_min = 4;  // compute twin: shortest run of empty records worth a walk (a walk restarts the request ring; docs/archive/tools/compute_mode.py)
     uint32_t probe_ahead = 2;    // skip kernels: request the next position's distance byte under the sample (0 never, 1 always, 2 single-frame launches)
     uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
     uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames

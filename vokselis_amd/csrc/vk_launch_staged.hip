@@ -10,13 +10,13 @@ using namespace vk;
 // LDS window per wave of the staged march: more LDS = thicker slabs (fewer rounds, each with its slab search, bounds
 // and fill) but fewer waves per CU.  The best budget depends on the view: what counts is the box an 8 x 8 pixel wave
 // sweeps per slab -- its footprint in cells (distance x pixel angle x n) plus the lateral drift of oblique rays -- and
-// the measured optimum (tools/staged_cameras.py: six cameras, C4 and C5) follows the bytes of that box for a slab of
+// the measured optimum (docs/archive/tools/staged_cameras.py: six cameras, C4 and C5) follows the bytes of that box for a slab of
 // T* = 4 cells (u8: at the VALU issue limit, occupancy first) or 6 cells (f16), in whole waves per CU between 5 KiB (8 waves
 // per SIMD) and 20 KiB (2): C5 from far away 5.83 -> 3.5 ms, from close by 38.4 -> 34.1 ms against a fixed 8 KiB.
 static uint32_t staged_cap_auto(const vk_ctx *ctx, const float *cam, bool u8, uint32_t *slab_cells) {
     const uint32_t fallback = u8 ? 6144u : 10240u;
     // the slab search's upper limit: the budget decides the thickness, this only bounds the search (6 / 8 cells until round 3 cut slabs short that
-    // would have fitted: C4 1.855 -> 1.78 ms at 16-24, C5 10.0 -> 9.76 at 16; tools/staged_group.py, profiles/r03_staged_group.txt)
+    // would have fitted: C4 1.855 -> 1.78 ms at 16-24, C5 10.0 -> 9.76 at 16; docs/archive/tools/staged_group.py, profiles/r03_staged_group.txt)
     *slab_cells = u8 ? 16u : 24u;
     if (!cam) return fallback;
     const float *m = cam + 20;
@@ -68,7 +68,7 @@ static void launch_staged_t(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
     // One window for the four waves of a 256-thread group (2 x 2 neighbouring 8x8 blocks) instead of one per wave: the rays of 16 x 16 pixels
     // sweep far less than four 8 x 8 boxes, so the slab is ~twice as thick and a ray meets half as many rounds -- against two barriers
-    // per round.  Measured (tools/staged_group.py, staged_group_sweep.py; frames bitwise equal): it pays where the wave is starved of LDS --
+    // per round.  Measured (docs/archive/tools/staged_group.py, staged_group_sweep.py; frames bitwise equal): it pays where the wave is starved of LDS --
     // u8 volumes seen from close by (C5: 10.05 -> 9.79 ms; four orbit frames per launch 9.25 -> 9.17; 6.25 KiB per wave and slabs up to 24 cells
     // read 9.83 single but 9.30 in the 4-frame launch: the per-wave budget stays) -- and costs where the budget is large
     // already (far views: a workgroup's 64 KiB is less than four waves' 80) or the launch is one partial round of waves (C4: single frame

@@ -81,7 +81,7 @@ static_assert(sizeof(RayState) == 64, "RayState is one 64-byte record");
 struct Census {  // SIMT execution census + step counters (COUNT builds only)
     uint32_t n_iter = 0, n_samp = 0, w_outer = 0, w_inner = 0, w_sample = 0, n_look = 0, n_fb = 0;
     uint32_t skips = 0;  // trips that skipped (every build: drives the adaptive probing policy)
-    // per-trip log of the wave (COUNT builds, debug bit 6; tools/repack_census.py): entry = live lanes | samplers << 7 | samplers whose alpha is
+    // per-trip log of the wave (COUNT builds, debug bit 6; docs/archive/tools/repack_census.py): entry = live lanes | samplers << 7 | samplers whose alpha is
     // not 0 << 14 | wave-level walk iterations << 21
     uint32_t *log = nullptr;
     uint32_t log_cap = 0, trip_no = 0;
@@ -108,7 +108,7 @@ struct Census {  // SIMT execution census + step counters (COUNT builds only)
 //              The number of iterations is the reference's whatever the walk does (`left` is exact), unless the alpha >= 0.95
 //              early-out flips (profiles/r04_walk_modes.txt).  No cap: a walk of any length costs the same dozen instructions.
 //   (Cutting the closed form at every binade boundary makes it exact again -- and 15 - 37 % slower than the loop: every crossing
-//   costs the lane another probing trip.  docs/history/experiments/skip_walk_binade_cut_closed_form.patch)
+//   costs the lane another probing trip.  docs/archive/experiments/skip_walk_binade_cut_closed_form.patch)
 enum WalkKind : int { WALK_LOOP = 0, WALK_FMA = 2 };
 
 //

@@ -86,7 +86,7 @@ int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags
         launch_compute(ctx, L, V, grid, count, ctx->vol_kind == VOL_PAIRB, !(flags & VK_RENDER_NO_SKIP));  // bricked 16-byte records, or the two dense volumes (the literal twin)
     } else {
         // Skipping costs a distance lookup per probing trip; it only pays when there is something to skip
-        // (tools/skip_crossover.py, DESIGN.md section 4: on 256^3 volumes with a share e of exactly-transparent cells
+        // (docs/archive/tools/skip_crossover.py, DESIGN.md section 4: on 256^3 volumes with a share e of exactly-transparent cells
         // the skip kernel overtakes the dense one between e = 0.36 and e = 0.56: 0.335 / 0.348 / 0.407 ms for dense /
         // adaptive / probing always at e = 0.36, 0.332 / 0.302 / 0.292 at e = 0.56).  Default policy by the census taken
         // at upload:  e < 0.45: the dense kernel;  0.45 <= e < 0.55: the skip kernel with adaptive probing (dense
