@@ -256,60 +256,43 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ctx.close()
 
 
-def c5_at_n(V, torch, dist, BatchTileRenderer, rank, world, local_rank, rehearsal, transport, frames=16, batch=4):
-    """BASELINE's own 8-GPU configuration (C5: 2048^3 u8, 3840x2160) through the N > 1 driver -- the same partition, gather and un-tile as
-    the headline's C2 frames -- with a fixed root and with a rotating one.  EVERY rank calls this (it is full of collectives); the ranks
-    agree on each set-up's outcome before they enter a timed window, and an exception inside a window is not caught (it ends the job
-    through the launcher instead of leaving the others parked in a barrier).  Returns the `extras.c5_at_n` object on rank 0."""
-    cfg = CONFIGS["c5"]
-    W, H, ts = cfg["W"], cfg["H"], tile_of(cfg)
-    stream = torch.cuda.Stream()
-    res = {"workload": cfg["name"], "frames_per_launch": batch, "timed_frames": frames, "tile": ts}
-    with torch.cuda.stream(stream):
-        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-        ctx = V.Context(W, H, cam, device=local_rank, backbuffer=(W, H), out_format=V.OUT_RGBA16F, stream=stream.cuda_stream)
+def c5_at_n(world, timeout_s=420):
+    """BASELINE's own 8-GPU configuration (C5: 2048^3 u8, 3840x2160) through the N > 1 driver -- the same partition, gather and un-tile as the
+    headline's C2 frames -- as a CHILD `bench.py --gpus N --config c5` with a time limit, started by rank 0 after this job's own ranks have left their
+    process group: a second job full of collectives must not be able to take the headline's line down (a hang or a crash in it costs `extras.c5_at_n`
+    an error string, nothing else).  Returns the `extras.c5_at_n` object."""
+    import signal
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                        "MASTER_ADDR", "MASTER_PORT", "VK_BENCH_TRANSPORT") and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--config", "c5", "--steps", "8", "--warmup", "2", "--no-extras", "--no-cpu-baseline"]
+    try:
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            res["volume_setup_s"] = make_volume(V, ctx, cfg, V.LAYOUT_AUTO)
-            ctx.update()
-            s_ref, s_samp = count_steps(ctx, V, 0)
-            res["s_ref_per_frame"], res["s_sampled_per_frame"] = s_ref, s_samp
-            pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE)
-            cams = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(batch)]
-            for name, root in (("fixed_root", 0), ("rotating_root", "rotate")):
-                btr, why = None, None
-                try:
-                    btr = BatchTileRenderer(ctx, pipe, tile_size=ts, batch=batch, root=root, transport=transport, via_host=rehearsal)
-                except Exception as e:  # noqa: BLE001
-                    why = repr(e)
-                okt = torch.tensor([0 if why else 1], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
-                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-                if not int(okt.item()):
-                    res[name] = {"error": why or "set-up failed on another rank"}
-                    if btr is not None:
-                        btr.close()
-                    continue
-
-                def window(k):
-                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for j in range(k):
-                        btr.submit(cams[j % batch])
-                    btr.flush()
-                    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    return float(tt.item())
-
-                window(2 * batch)
-                el = sorted(window(frames) for _ in range(3))[1]
-                res[name] = {"ms_per_frame": el / frames * 1e3, "value": s_ref * frames / el / 1e6, "unit": "Mray-steps/s", "root_skip": btr.root_skip,
-                             "frac": (s_samp * cfg["b_step"] + W * H * B_RAY) * frames / el / 1e9 / (HBM_PEAK_GBS * world)}
-                btr.close()
-        finally:
-            ctx.close()
-    res["note"] = ("C5 frames through the N > 1 driver (64 x 64-pixel tiles dealt heaviest-first, one launch + one gather + one un-tile per batch), median of "
-                   "three windows, max over ranks; the volume is replicated on every GPU (26 GB of 288)")
-    return res if rank == 0 else None
+            so, se = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            return {"error": "the C5 job did not finish within %d s" % timeout_s}
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": "the C5 job failed (rc %d): %s" % (proc.returncode, se[-400:])}
+        d = json.loads(lines[-1])
+        res = {"workload": d["config"]["workload"], "n_gpus": d["n_gpus"], "frames_per_launch": d["frames_per_launch"], "timed_frames": d["timed_frames"],
+               "s_ref_per_frame": d["config"]["s_ref_config_camera"], "volume_setup_s": d.get("volume_setup_s"),
+               "fixed_root": {"value": d["value"], "unit": d["unit"], "ms_per_frame": d["ms_per_step"], "frac": d["roofline"]["frac"], "root_skip": d["config"].get("root_skip")},
+               "note": "`bench.py --gpus %d --config c5` as a child job after this one's ranks left their process group: C5 frames through the same partition + "
+                       "gather + un-tile as the headline's (64 x 64-pixel tiles dealt heaviest-first, volume replicated: 26 GB of 288 per GPU)" % world}
+        if "rotating_root" in d:
+            rr = d["rotating_root"]
+            res["rotating_root"] = rr if "error" in rr else {"value": rr["value"], "unit": rr["unit"], "ms_per_frame": rr["ms_per_step"]}
+        if "rehearsal" in d:
+            res["rehearsal"] = d["rehearsal"]
+        return res
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def self_launch(args):
@@ -954,14 +937,12 @@ def main():
                     out["extras"][name] = big_config_extra(V, torch, local_rank, key)
                 except Exception as e:
                     out["extras"][name] = {"error": str(e)}
-    # N > 1: BASELINE's 8-GPU configuration through the same driver, after the C2 context is gone.  Every rank takes part.
-    if use_dist and world > 1 and args.config == "c2" and not args.no_extras and os.environ.get("VK_BENCH_C5_AT_N", "1") != "0":
-        r5 = c5_at_n(V, torch, dist, BatchTileRenderer, rank, world, local_rank, rehearsal, transport)
-        if rank == 0:
-            out.setdefault("extras", {})["c5_at_n"] = r5
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # N > 1: BASELINE's 8-GPU configuration through the same driver -- a child job, once this one's ranks are out of their collectives
+    if rank == 0 and world > 1 and args.config == "c2" and not args.no_extras and os.environ.get("VK_BENCH_C5_AT_N", "1") != "0":
+        out.setdefault("extras", {})["c5_at_n"] = c5_at_n(world)
     if rank == 0:
         # RCCL writes a version banner through C stdio; flush it first so the JSON line is the last line
         try:
