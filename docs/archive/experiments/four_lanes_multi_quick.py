@@ -48,5 +48,6 @@ for rep in range(2):
     for n in tiles:
       for thr in (thrs if n else thrs[:1]):
         ctx.set_param("multi_tiles", n); ctx.set_param("multi_thr", thr)
-        print(json.dumps({"multi_tiles": n, "multi_thr": thr, "single_ms": round(t(ctx, lambda: p.record(ctx), 50), 4), "crc": crc[(n, thr)]}), flush=True)
+        ms = t(ctx, lambda: p.record(ctx), 50)
+        print(json.dumps({"multi_tiles": n, "multi_thr": thr, "single_ms": round(ms, 4), "crc": crc[(n, thr)], "crc16f": "%08x" % zlib.crc32(ctx.read_backbuffer().tobytes())}), flush=True)
 ctx.close()
