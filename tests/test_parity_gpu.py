@@ -905,25 +905,32 @@ def test_cameras_dims_and_dt(V, O):
 
 def test_trip_budget_against_the_oracle_loop(V, O):
     """The march carries an integer trip budget computed by vk::count_trips on the device (vokselis_amd/csrc/vk_trips.hpp) instead of the loop variable of
-    raycast_naive.wgsl:101.  On fog that never reaches the early-out a pixel's step count IS that trip count: per-pixel equality with the oracle -- which runs
-    the loop itself, `for (t = t0; t < t1; t += dt)` -- for eyes far outside (t in the binades [2, 4) .. [8, 16)), inside the volume (t starts at 0 and climbs
+    raycast_naive.wgsl:101.  Through air (alpha exactly 0: no early-out) a pixel's step count IS that trip count, through fog nearly so: per-pixel equality with
+    the oracle -- which runs the loop itself, `for (t = t0; t < t1; t += dt)` -- for eyes far outside (t in the binades [2, 4) .. [8, 16)), inside the volume (t starts at 0 and climbs
     through every binade), on a face, and for step lengths from 0.02 to 3 cells; dense march and skip kernel (nothing to skip: forced), two layouts."""
     rng = np.random.default_rng(5)
     n = 48
-    vol = rng.integers(26, 32, (n, n, n)).astype(np.uint8)  # alpha per step <= 2e-3: never 0.95 in 48 * sqrt(3) / 0.02 steps? (checked below)
+    vol = rng.integers(26, 32, (n, n, n)).astype(np.uint8)  # fog: alpha per step ~1e-3
+    air = rng.integers(0, 26, (n, n, n)).astype(np.uint8)   # air: alpha exactly 0 in every step
     cases = [(6.0, 0.3, 1.0, (0.5, 0.5, 0.5)), (11.0, -0.7, 4.0, (0.5, 0.5, 0.5)), (3.1, 1.3, 2.2, (0.5, 0.5, 0.5)),   # far: t0 ~ 2.6 .. 10.5
              (0.2, 0.4, 0.9, (0.5, 0.5, 0.5)), (0.05, -0.2, 5.0, (0.3, 0.6, 0.5)),                                       # inside: t0 = 0
              (0.5, 0.0, 0.0, (0.5, 0.5, 0.5)), (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))]                                        # eye on the z = 0 face; the bonsai camera
     W, H = 72, 56
     for ci, (zoom, pitch, yaw, target) in enumerate(cases):
         cam = O.camera_blob(zoom, pitch, yaw, target, W / H)
-        for dt in ((0.02, 0.37, 1.0, 3.0) if ci % 2 == 0 else (0.11, 0.5, 1.9)):
+        for dt in ((0.02, 0.37, 1.0, 3.0) if ci % 2 == 0 else (0.11, 0.5, 1.9)) + ((0.003,) if ci in (1, 3) else ()):  # (0.003: ~28 000 iterations per ray)
             ref, rsteps, _ = O.render(cam, vol, W, H, dt_scale=dt)
-            assert float(ref[..., :3].max()) < 1.0  # (no ray saturated: the counts below are trip counts)
             for lay, fl in ((V.LAYOUT_PACKED_PAIRS, V.RENDER_NO_SKIP), (V.LAYOUT_PACKED_PAIRS, V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS), (V.LAYOUT_PACKED, V.RENDER_SAFE)):
                 img, steps, _ = gpu_render(V, cam, vol, W, H, dt=dt, layout=lay, flags=fl)
                 assert (steps == rsteps).all(), (ci, dt, lay, fl, int((steps != rsteps).sum()))
                 assert np.abs(img - ref).max() <= TOL, (ci, dt, lay, fl)
+            # ... and through air (every tap <= 25: alpha exactly 0, no early-out whatever the length): the dense kernel makes every iteration, the skip
+            # kernel makes none of them but walks -- its walks are clamped to the iterations left, so the count it reports is the budget itself
+            ref0, rsteps0, _ = O.render(cam, air, W, H, dt_scale=dt)
+            for fl in (V.RENDER_NO_SKIP, V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS, 0):
+                img, steps, (_, s_samp) = gpu_render(V, cam, air, W, H, dt=dt, layout=V.LAYOUT_PACKED_PAIRS, flags=fl)
+                assert (steps == rsteps0).all(), (ci, dt, fl, int((steps != rsteps0).sum()))
+                assert (img == ref0).all() and (fl == V.RENDER_NO_SKIP or s_samp == 0), (ci, dt, fl)
 
 
 def test_skip_fuzz_cameras_dims_dt(V, O):
