@@ -107,6 +107,51 @@ __global__ __launch_bounds__(64) void fill_march_kernel(Params P, unsigned long 
     };
     if (MODE == 1) request(0);
     unsigned long long acc = 0;
+    if (MODE == 0 && (P.coherent & 2u)) {
+        // stagger: waves that start together and do the same work fill at the same time and march at the same time; offset them by a fraction of a round's steps
+        const unsigned phase = (blockIdx.x * 2654435761u >> 28) & 7u;  // 0 .. 7 eighths of a round
+        for (unsigned t = 0; t < P.think * phase / 8u; t++)
+            asm volatile("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n"
+                         "v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d));
+    }
+    if (MODE == 2) {
+        // a rolling ring of slices: one LDS-DMA per cell of progress, K = P.Es - 1 slices requested ahead of the one being marched, the wait is for
+        // the OLDEST slice only (vmcnt counts loads in order); the steps of one cell (think / T instructions) run under the rest
+        const unsigned voff = voff_of(0);
+        const unsigned K = P.Es - 1u, ringB = P.Es * slicePieces * 16u;
+        unsigned keep_m0;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+        unsigned issued = 0;
+        auto issue = [&]() {
+            if (lane < slicePieces) {
+                const unsigned dst = win_lds + (issued % P.Es) * slicePieces * 16u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src_of(0, issued)), "s"(dst) : "memory");
+            }
+            issued++;
+        };
+        for (unsigned k = 0; k < K; k++) issue();
+        const unsigned cells = P.rounds * P.advance, per_cell = P.think / P.advance;
+        for (unsigned c = 0; c < cells; c++) {
+            issue();
+            // K loads may stay in flight: the slice of cell c (issued K + 1 loads ago) has landed
+            if (K >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (K == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            acc += *reinterpret_cast<unsigned *>(win + ((lane * 16u) % ringB));
+            for (unsigned t = 0; t < per_cell; t++)
+                asm volatile("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n"
+                             "v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d));
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_mov_b32 m0, %0" : : "s"(keep_m0) : "memory");
+        if (acc + (unsigned long long)(a0 + a1 + a2 + a3) == 0x1234567ull) sink[0] = acc;
+        return;
+    }
     for (unsigned r = 0; r < P.rounds; r++) {
         if (MODE == 0) {
             const unsigned voff = voff_of(r);
@@ -264,21 +309,54 @@ int main(int argc, char **argv) {
     printf("%-10s %7s %6s %6s | %12s %12s\n", "mode", "LDS B", "w/SIMD", "think", "us per round", "slab-cells/us");
     for (unsigned lds : {10240u, 12288u, 8192u})
         for (unsigned think : {0u, 40u, 80u, 160u})
-            for (int mode = 0; mode < 2; mode++) {
-                Params P{tab, layerB, nb, nb, nb * copies, 7, 16, 3, 0, 6, think, 1};
+            for (int mode = 0; mode < 4; mode++) {
+                // (modes 2, 3: the rolling ring -- the same LDS, 6 / 3 slices requested ahead, the remaining slots of the window marched from)
+                Params P{tab, layerB, nb, nb, nb * copies, mode == 3 ? 4u : 7u, 16, 3, 0, 6, think, 1};
                 const unsigned waves_per_cu = std::min(32u, 163840u / lds);
                 const unsigned blocks = 256u * waves_per_cu * 4u;
                 P.rounds = 64;
                 for (int rep = 0; rep < 2; rep++) {
                     CHECK(hipEventRecord(e0));
                     if (mode == 0) hipLaunchKernelGGL(fill_march_kernel<0>, dim3(blocks), dim3(64), lds, 0, P, sink);
-                    else hipLaunchKernelGGL(fill_march_kernel<1>, dim3(blocks), dim3(64), lds, 0, P, sink);
+                    else if (mode == 1) hipLaunchKernelGGL(fill_march_kernel<1>, dim3(blocks), dim3(64), lds, 0, P, sink);
+                    else hipLaunchKernelGGL(fill_march_kernel<2>, dim3(blocks), dim3(64), lds, 0, P, sink);
                     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 }
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 // a SIMD's time per round of one of its waves: launch time / (rounds x waves the SIMD ran)
-                printf("%-10s %7u %6.1f %6u | %12.3f %12.0f\n", mode ? "registers" : "lds-dma", lds, waves_per_cu / 4.0, think * 8u, ms * 1e3 / (P.rounds * 4.0 * waves_per_cu / 4.0),
+                printf("%-10s %7u %6.1f %6u | %12.3f %12.0f\n", mode == 0 ? "lds-dma" : (mode == 1 ? "registers" : (mode == 2 ? "ring K=6" : "ring K=3")), lds, waves_per_cu / 4.0, think * 8u, ms * 1e3 / (P.rounds * 4.0 * waves_per_cu / 4.0),
                        (double)blocks * P.rounds * P.advance / ms / 1e3);
             }
+    // the convoy: blocking fills with and without a staggered start
+    printf("# blocking fills, box 7 x 16 x 3 (T = 6): all waves start in phase, against a start staggered by 0 .. 7 eighths of a round's steps\n");
+    printf("%-10s %7s %6s %6s | %12s\n", "start", "LDS B", "w/SIMD", "think", "slab-cells/us");
+    for (unsigned lds : {10240u, 12288u})
+        for (unsigned think : {80u, 160u})
+            for (unsigned stag : {0u, 1u}) {
+                Params P{tab, layerB, nb, nb, nb * copies, 7, 16, 3, 256, 6, think, 1u | (stag << 1)};
+                const unsigned waves_per_cu = std::min(32u, 163840u / lds);
+                const unsigned blocks = 256u * waves_per_cu * 4u;
+                for (int rep = 0; rep < 2; rep++) {
+                    CHECK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(fill_march_kernel<0>, dim3(blocks), dim3(64), lds, 0, P, sink);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                }
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                printf("%-10s %7u %6.1f %6u | %12.0f\n", stag ? "staggered" : "in phase", lds, waves_per_cu / 4.0, think * 8u, (double)blocks * P.rounds * P.advance / ms / 1e3);
+            }
+    // the latency of ONE fill: a single wave per CU (256 workgroups; then one per SIMD, two per SIMD), blocking fills back to back, nothing else on the machine
+    printf("# latency of a blocking fill (box 7 x 16 x 3 = 5.4 KB in 7 LDS-DMA instructions) against the waves that fill at the same time\n");
+    printf("%-24s | %14s\n", "waves on the machine", "us per fill");
+    for (unsigned waves : {256u, 1024u, 2048u, 4096u, 8192u, 16384u}) {
+        Params P{tab, layerB, nb, nb, nb * copies, 7, 16, 3, 64, 6, 0, 1};
+        const unsigned lds = waves <= 4096u ? 40960u : (waves == 8192u ? 20480u : 10240u);  // (caps the waves per CU at 4 / 8 / 16)
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(fill_march_kernel<0>, dim3(waves), dim3(64), lds, 0, P, sink);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        }
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-24u | %14.3f\n", waves, ms * 1e3 / P.rounds);
+    }
     return 0;
 }
