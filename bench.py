@@ -256,7 +256,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ctx.close()
 
 
-def c5_at_n(world, timeout_s=420):
+def c5_at_n(world, timeout_s=240):
     """BASELINE's own 8-GPU configuration (C5: 2048^3 u8, 3840x2160) through the N > 1 driver -- the same partition, gather and un-tile as the
     headline's C2 frames -- as a CHILD `bench.py --gpus N --config c5` with a time limit, started by rank 0 after this job's own ranks have left their
     process group: a second job full of collectives must not be able to take the headline's line down (a hang or a crash in it costs `extras.c5_at_n`
