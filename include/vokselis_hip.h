@@ -9,8 +9,8 @@
  *
  * Conventions: 0 = VK_OK, negative = error, nothing aborts or throws across the boundary.
  * The caller owns every host pointer; the library owns all device memory it allocates.  A
- * vk_ctx is bound to one GPU and one HIP stream and is not thread-safe (the reference drives
- * its queue from the single winit thread, src/lib.rs:71).
+ * vk_ctx is bound to one GPU and one HIP stream (one per frame slot with frames in flight) and is
+ * not thread-safe (the reference drives its queue from the single winit thread, src/lib.rs:71).
  */
 #ifndef VOKSELIS_HIP_H
 #define VOKSELIS_HIP_H
@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4
+#define VK_ABI_VERSION 5
 
 typedef struct vk_ctx vk_ctx;
 
@@ -144,6 +144,42 @@ int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_f
 int vk_backbuffer_info(vk_ctx *ctx, uint32_t *width, uint32_t *height, int *out_format, void **device_ptr);
 /* Clear to the render pass's LoadOp::Clear(BLACK) = (0,0,0,1), examples/bonsai/main.rs:41. */
 int vk_backbuffer_clear(vk_ctx *ctx);
+
+/* ---- frames in flight (ABI 5) -------------------------------------------------------------- */
+/* The reference records ONE pass per frame and lets its queue run ahead of the GPU: RedrawRequested calls demo.render and
+ * Context::render without waiting for the previous frame (src/lib.rs:178-194); Surface::get_current_texture blocks only
+ * when every swapchain image is still in use (src/context.rs:252, PresentMode::Fifo at :118).  A frame that is 70 % empty
+ * cannot fill the machine on its own, and a caller that learns its camera one frame at a time cannot use vk_render_batch.
+ * With k > 1 the context owns a ring of k frame slots -- backbuffer, present targets and step image of their own, each on
+ * its own HIP stream -- and the calls between vk_frame_begin and vk_frame_end go to the slot of that frame, so the first
+ * waves of frame i + 1 fill the SIMDs that the tail of frame i leaves idle.  k = 1 (the default) is one slot on the
+ * context's stream: the behaviour of ABI 4.  Every frame is bitwise the frame the same calls produce with k = 1.
+ *
+ * vk_ctx_frames_in_flight: 1 <= k <= VK_MAX_FRAMES_IN_FLIGHT; drains the context, sizes the ring (new slots take the
+ *   backbuffer's current shape, cleared) and forgets earlier frame ids.  Refused while a frame is open, and for k > 1 on a
+ *   context that runs on a caller's stream (vk_ctx_set_stream).
+ * vk_frame_begin (get_current_texture): takes the next slot of the ring, BLOCKING the host until the frame that used it
+ *   k frames ago has completed -- at most k frames are ever in flight; with k = 1 the frames follow one another on one
+ *   stream and nothing blocks -- and makes it the context's current surface:
+ *   vk_render, vk_backbuffer_clear, vk_present, vk_readback, vk_capture_frame, vk_backbuffer_info and the timers address
+ *   it.  *frame_id (>= 1, increasing) names the frame.
+ * vk_frame_end (queue.submit + frame.present, src/context.rs:294-296): marks the end of the frame's work.
+ * vk_frame_wait: blocks until that frame's work has completed (a frame whose slot has been taken again completed long ago).
+ * vk_frame_readback / vk_frame_capture: vk_readback / vk_capture_frame of THAT frame, while its slot still holds it
+ *   (VK_ERR_INVALID once a later vk_frame_begin has taken the slot); they wait for the frame only, not for the frames
+ *   submitted after it.
+ * vk_frame_info: the frame's device buffers (backbuffer; Rgba8 present target or NULL) for consumers on the device -- order
+ *   them after vk_frame_wait, and finish with them before the vk_frame_begin that reuses the slot k frames later.
+ * Outside begin / end the context behaves as before on its current slot.  vk_ctx_sync drains every slot. */
+#define VK_MAX_FRAMES_IN_FLIGHT 4
+int vk_ctx_frames_in_flight(vk_ctx *ctx, uint32_t k);
+int vk_frame_begin(vk_ctx *ctx, uint64_t *frame_id);
+int vk_frame_end(vk_ctx *ctx);
+int vk_frame_wait(vk_ctx *ctx, uint64_t frame_id);
+int vk_frame_readback(vk_ctx *ctx, uint64_t frame_id, void *dst, size_t row_pitch_bytes);
+int vk_frame_capture(vk_ctx *ctx, uint64_t frame_id, void *dst, size_t dst_bytes, uint32_t *out_width, uint32_t *out_height,
+                     uint32_t *out_padded_bytes_per_row);
+int vk_frame_info(vk_ctx *ctx, uint64_t frame_id, void **backbuffer, void **rgba8, int *complete);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* One raycast pass over a tile of the backbuffer, asynchronous on the context's stream.

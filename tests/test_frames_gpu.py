@@ -1,0 +1,221 @@
+"""GPU suite, frames in flight (vk_ctx_frames_in_flight / vk_frame_*): the reference's submission model -- one pass per frame, the
+queue running ahead of the GPU (src/lib.rs:178-194, src/context.rs:118,252) -- on a ring of K frame surfaces, each on its own stream.
+
+Bars: every frame bitwise the frame the same calls produce with one surface (and within 1e-4 of the oracle); a frame's surface is not
+written again before the frame K later begins; error codes, never crashes, for misuse.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+W, H, DT = 480, 270, 0.5
+
+
+@pytest.fixture(scope="module")
+def V(hip_built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU: the gpu suite must run on an MI355X box")
+    import vokselis_amd
+
+    return vokselis_amd
+
+
+def orbit(V, n, aspect=W / H, target=(0.5, 0.5, 0.5), zoom=1.0, pitch=0.5):
+    return [V.Camera(zoom, pitch + 0.02 * j, 1.0 + 0.05 * j, target, aspect).get_proj_view_matrix() for j in range(n)]
+
+
+def bonsai_ctx(V, k=1, out=None):
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F if out is None else out)
+    V.VolumeTexture.generate_standin(ctx, (256,) * 3)
+    if k > 1:
+        ctx.frames_in_flight(k)
+    return ctx
+
+
+def test_frames_in_flight_bitwise_and_oracle(V, O):
+    cams = orbit(V, 7)
+    pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT)
+    # one surface, one stream: the frames every ring has to reproduce
+    ctx = bonsai_ctx(V)
+    ref, shots = [], []
+    try:
+        for cb in cams:
+            ctx.set_camera_blob(cb)
+            pipe.record(ctx)
+            ctx.render()
+            ref.append(ctx.read_backbuffer())
+            shots.append(ctx.capture_frame()[0])
+    finally:
+        ctx.close()
+    want, wsteps, _ = O.render(cams[0], O.volume_standin_u8(256), W, H, dt_scale=DT)
+    assert np.abs(ref[0] - want).max() <= TOL
+    for k in (1, 2, 3, 4):
+        ctx = bonsai_ctx(V, k)
+        try:
+            ids, ptrs = [], []
+            for j, cb in enumerate(cams):
+                ctx.set_camera_blob(cb)  # a camera the caller did not know a frame earlier
+                fid = ctx.frame_begin()
+                pipe.record(ctx)
+                ctx.render()
+                ctx.frame_end()
+                ids.append(fid)
+                ptrs.append(ctx.frame_info(fid)["backbuffer"])
+                if j >= 1 and k >= 2:
+                    # the hazard: frame j (another camera) is in flight behind frame j - 1; j - 1's surface holds j - 1's pixels
+                    prev = ctx.read_frame(ids[j - 1])
+                    assert (prev.view(np.uint8) == ref[j - 1].view(np.uint8)).all(), (k, j)
+            assert ids == list(range(ids[0], ids[0] + len(cams)))
+            # the ring: k distinct surfaces, frame j + k on frame j's
+            assert len(set(ptrs[:k])) == k and all(ptrs[j] == ptrs[j - k] for j in range(k, len(cams)))
+            for j in range(len(cams)):
+                if j >= len(cams) - k:  # still held
+                    got = ctx.read_frame(ids[j])
+                    assert (got.view(np.uint8) == ref[j].view(np.uint8)).all(), (k, j)
+                    assert ctx.capture_frame_of(ids[j])[0] == shots[j], (k, j)
+                    assert ctx.frame_info(ids[j])["complete"]
+                else:  # its surface went to frame j + k
+                    with pytest.raises(V.VokselisError):
+                        ctx.read_frame(ids[j])
+                    ctx.frame_wait(ids[j])  # (completed long ago: not an error)
+            # the current surface is the last frame's
+            assert (ctx.read_backbuffer().view(np.uint8) == ref[-1].view(np.uint8)).all()
+            with pytest.raises(V.VokselisError):
+                ctx.frame_wait(ids[-1] + 1)
+        finally:
+            ctx.close()
+
+
+def test_frames_in_flight_tile_loop(V):
+    """The xor example's frame -- 18 tile dispatches with offsets (examples/xor/main.rs:235-254) -- with frames in flight: every tile
+    launch takes a slot of the tile-order ring (16 slots), so the ring comes round INSIDE every frame and the next frame, on another
+    stream, rewrites slots the previous frame's launches read."""
+    w, h, ts = 1280, 720, 256
+    cams = [V.Camera(3.0, -0.5 + 0.03 * j, 1.0 + 0.1 * j, (0.0, 0.0, 0.0), w / h).get_proj_view_matrix() for j in range(5)]
+    offsets = [(x * ts, y * ts) for y in range(h // ts + 1) for x in range(w // ts + 1)]
+    assert len(offsets) == 18
+    pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST)
+    frames = {}
+    for k in (1, 3):
+        ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
+        try:
+            V.VolumeTexture.generate_xor(ctx, (64,) * 3, 0.0)
+            if k > 1:
+                ctx.frames_in_flight(k)
+            got = []
+            ids = []
+            for cb in cams:
+                ctx.set_camera_blob(cb)
+                ids.append(ctx.frame_begin())
+                for (x, y) in offsets:
+                    pipe.record(ctx, (x, y, ts, ts))
+                ctx.frame_end()
+                if k == 1:
+                    got.append(ctx.read_backbuffer())
+            if k > 1:
+                got = [None] * (len(cams) - k) + [ctx.read_frame(i) for i in ids[-k:]]
+            frames[k] = got
+        finally:
+            ctx.close()
+    for j in range(len(cams) - 3, len(cams)):
+        assert (frames[3][j].view(np.uint8) == frames[1][j].view(np.uint8)).all(), j
+    assert frames[1][0].astype(np.float32)[..., :3].max() > 0.1  # (something was drawn)
+
+
+def test_frames_in_flight_misuse_is_an_error_code(V):
+    import torch
+
+    ctx = bonsai_ctx(V)
+    try:
+        for bad in (0, V.native.MAX_FRAMES_IN_FLIGHT + 1):
+            with pytest.raises(V.VokselisError):
+                ctx.frames_in_flight(bad)
+        with pytest.raises(V.VokselisError):
+            ctx.frame_end()  # no frame open
+        ctx.frames_in_flight(2)
+        with pytest.raises(V.VokselisError):
+            ctx.set_stream(torch.cuda.Stream().cuda_stream)  # the ring's surfaces run on streams of the context's own
+        ctx.set_camera_blob(orbit(V, 1)[0])
+        fid = ctx.frame_begin()
+        with pytest.raises(V.VokselisError):
+            ctx.frame_begin()  # one frame open at a time
+        with pytest.raises(V.VokselisError):
+            ctx.frames_in_flight(3)
+        with pytest.raises(V.VokselisError):
+            ctx.resize_backbuffer(64, 64)
+        with pytest.raises(V.VokselisError):
+            ctx.read_frame(fid)  # still open
+        V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT).record(ctx)
+        ctx.frame_end()
+        a = ctx.read_frame(fid)
+        # a new volume while frames are in flight: the ring is drained, the next frame sees the new volume
+        V.VolumeTexture.generate_fog(ctx, (64,) * 3)
+        f2 = ctx.frame_begin()
+        V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT).record(ctx)
+        ctx.frame_end()
+        b = ctx.read_frame(f2)
+        assert not (a == b).all()
+        # a smaller ring, then one surface again: earlier ids are forgotten, the context keeps working
+        ctx.frames_in_flight(1)
+        with pytest.raises(V.VokselisError):
+            ctx.read_frame(f2)
+        f3 = ctx.frame_begin()
+        V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT).record(ctx)
+        ctx.frame_end()
+        assert f3 > f2 and (ctx.read_frame(f3).view(np.uint8) == b.view(np.uint8)).all()
+        # resize with a ring: every surface takes the new shape
+        ctx.frames_in_flight(3)
+        ctx.resize_backbuffer(96, 64)
+        ids = []
+        for _ in range(3):
+            ids.append(ctx.frame_begin())
+            V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT).record(ctx)
+            ctx.frame_end()
+        got = [ctx.read_frame(i) for i in ids]
+        assert got[0].shape == (64, 96, 4) and all((g.view(np.uint8) == got[0].view(np.uint8)).all() for g in got)
+    finally:
+        ctx.close()
+    # a context on a caller's stream cannot grow a ring
+    s = torch.cuda.Stream()
+    ctx = V.Context(W, H, backbuffer=(W, H), stream=s.cuda_stream)
+    try:
+        with pytest.raises(V.VokselisError):
+            ctx.frames_in_flight(2)
+        ctx.frames_in_flight(1)
+    finally:
+        ctx.close()
+
+
+def test_run_headless_in_flight(V):
+    """run::<D> (src/lib.rs:45-208) with the queue running ahead: the last frame equals the one-surface run's."""
+
+    class Bonsai(V.Demo):
+        @classmethod
+        def init(cls, ctx):
+            self = cls()
+            self.volume = V.VolumeTexture.generate_standin(ctx, (64,) * 3)
+            self.pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR)
+            return self
+
+        def update(self, ctx):
+            ctx.camera.add_yaw(0.1)  # a mouse drag (src/lib.rs:166-171)
+
+        def render(self, ctx):
+            self.pipe.record(ctx)
+
+    shots = {}
+    for k in (1, 3):
+        seen = []
+        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 160 / 90)
+        ctx, _ = V.run_headless(Bonsai, frames=5, camera=cam, width=160, height=90, backbuffer=(160, 90), in_flight=k,
+                                on_frame=lambda c, fid: seen.append(fid))
+        try:
+            assert seen == [1, 2, 3, 4, 5]
+            shots[k] = (ctx.read_backbuffer(), ctx.capture_frame()[0])
+        finally:
+            ctx.close()
+    assert (shots[1][0].view(np.uint8) == shots[3][0].view(np.uint8)).all() and shots[1][1] == shots[3][1]

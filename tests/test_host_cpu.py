@@ -21,7 +21,7 @@ def test_cabi_exports_every_declared_symbol(hip_built):
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert getattr(hip_built, name) is not None
-    assert hip_built.vk_abi_version() == 4  # round 2: batch, comm, group entry points; round 3: vk_partition_wire, vk_wire_pixel_bytes, 1024 frames per batch; round 4: vk_comm_available, vk_group_peer_direct, VK_RENDER_FAST_WALK, a rank's share in whole-frame addressing
+    assert hip_built.vk_abi_version() == 5  # round 6: frames in flight (vk_ctx_frames_in_flight, vk_frame_*); round 2: batch, comm, group entry points; round 3: vk_partition_wire, vk_wire_pixel_bytes, 1024 frames per batch; round 4: vk_comm_available, vk_group_peer_direct, VK_RENDER_FAST_WALK, a rank's share in whole-frame addressing
 
 
 def test_cabi_fails_loudly_without_gpu(hip_built):

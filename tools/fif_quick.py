@@ -1,0 +1,63 @@
+"""Frames in flight in a few seconds: ms per frame of the one-vk_render-per-frame surface, every frame a new orbit camera, on one
+surface / one stream (today's vk_render loop) and on rings of K = 1..4 surfaces (vk_ctx_frames_in_flight), for C2 (bonsai stand-in
+256^3, 1080p, dt_scale 0.5) and the xor example's own frame (256^3 pair, 1280x720).  Wall time around N frames, best of three.
+usage: tools/fif_quick.py [--frames N] [--present]"""
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import variant
+variant.use_variant_from_env()
+import torch  # noqa: F401  (one HIP runtime per process: see vokselis_amd/_native.py)
+import vokselis_amd as V
+
+n = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
+present = "--present" in sys.argv
+
+
+def stream_of_frames(ctx, pipe, cams, frames_api):
+    """ms per frame, wall time: set_camera -> [frame_begin] -> vk_render [-> vk_present] -> [frame_end] for every camera."""
+    def once(k):
+        for j in range(k):
+            ctx.set_camera_blob(cams[j % len(cams)])
+            if frames_api:
+                ctx.frame_begin()
+            pipe.record(ctx)
+            if present:
+                ctx.render()
+            if frames_api:
+                ctx.frame_end()
+    once(64)
+    ctx.sync()
+    best, host = 1e9, 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        once(n)
+        t1 = time.perf_counter()
+        ctx.sync()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        host = min(host, (t1 - t0) / n * 1e3)
+    return best, host
+
+
+out = {"lib": os.environ.get("VK_LIB", "product"), "frames": n, "present": present}
+for name, (w, h), mk, mode, dt, cam0 in (
+        ("c2", (1920, 1080), lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
+        ("xor720p", (1280, 720), lambda c: V.VolumeTexture.generate_xor(c, (256,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))):
+    ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
+    mk(ctx)
+    z, p, y, t = cam0
+    cams = [V.Camera(z, p, y + 6.28318 * j / 1024, t, w / h).get_proj_view_matrix() for j in range(128)]
+    pipe = V.RaycastPipeline(mode, dt_scale=dt)
+    ctx.set_camera_blob(cams[0])
+    for _ in range(200):
+        pipe.record(ctx)  # clocks
+    r5 = lambda t: (round(t[0], 5), round(t[1], 5))  # (ms per frame, of which the host spent submitting)
+    res = {"plain": r5(stream_of_frames(ctx, pipe, cams, False))}
+    for k in (1, 2, 3, 4):
+        ctx.frames_in_flight(k)
+        res["k%d" % k] = r5(stream_of_frames(ctx, pipe, cams, True))
+    ctx.frames_in_flight(1)
+    res["plain_again"] = r5(stream_of_frames(ctx, pipe, cams, False))
+    out[name] = res
+    ctx.close()
+print(json.dumps(out), flush=True)

@@ -19,6 +19,7 @@ RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS, RENDER_FAST_WALK = 32, 64, 128
 WIRE_RGBA, WIRE_RGB = 0, 1
+MAX_FRAMES_IN_FLIGHT = 4
 GEN_FOG, GEN_BONSAI_STANDIN, GEN_FOG_DENSE_CORE = 0, 1, 2
 
 # every symbol include/vokselis_hip.h declares: name -> (restype, argtypes)
@@ -42,6 +43,13 @@ SYMBOLS = {
     "vk_backbuffer_resize": (C.c_int, [_vp, _u32, _u32, C.c_int]),
     "vk_backbuffer_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_int), C.POINTER(_vp)]),
     "vk_backbuffer_clear": (C.c_int, [_vp]),
+    "vk_ctx_frames_in_flight": (C.c_int, [_vp, _u32]),
+    "vk_frame_begin": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "vk_frame_end": (C.c_int, [_vp]),
+    "vk_frame_wait": (C.c_int, [_vp, C.c_uint64]),
+    "vk_frame_readback": (C.c_int, [_vp, C.c_uint64, _vp, _sz]),
+    "vk_frame_capture": (C.c_int, [_vp, C.c_uint64, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "vk_frame_info": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
     "vk_render": (C.c_int, [_vp, C.c_int, _i32, _i32, _u32, _u32, _f32, _u32]),
     "vk_partition_slots": (C.c_int, [_u32, _u32, _u32, _u32, C.POINTER(_u32)]),
     "vk_partition_slots_weighted": (C.c_int, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),

@@ -120,6 +120,7 @@ class Context:
         N.check(self._h, L.vk_backbuffer_resize(self._h, bw, bh, out_format))
         self._timeline = time.perf_counter()
         self._first_frame = True
+        self.in_flight = 1
 
     # -- lifetime
     def close(self):
@@ -189,6 +190,45 @@ class Context:
 
     def sync(self):
         N.check(self._h, N.lib().vk_ctx_sync(self._h))
+
+    # -- frames in flight: the queue running ahead of the GPU (src/lib.rs:178-194), bounded by the swapchain (src/context.rs:118,252)
+    def frames_in_flight(self, k: int):
+        """vk_ctx_frames_in_flight: a ring of k frame surfaces, each on its own stream (1: one surface, the default)."""
+        N.check(self._h, N.lib().vk_ctx_frames_in_flight(self._h, int(k)))
+        self.in_flight = int(k)
+
+    def frame_begin(self) -> int:
+        """Surface::get_current_texture (src/context.rs:252): the next surface of the ring (blocks while the frame that used it k
+        frames ago is still running); the render / present / read calls that follow address it.  Returns the frame's id."""
+        fid = C.c_uint64()
+        N.check(self._h, N.lib().vk_frame_begin(self._h, C.byref(fid)))
+        return fid.value
+
+    def frame_end(self):
+        """queue.submit + frame.present() (src/context.rs:294-296)."""
+        N.check(self._h, N.lib().vk_frame_end(self._h))
+
+    def frame_wait(self, frame_id: int):
+        N.check(self._h, N.lib().vk_frame_wait(self._h, frame_id))
+
+    def read_frame(self, frame_id: int) -> np.ndarray:
+        """vk_frame_readback: that frame's backbuffer (waits for that frame only), while its surface still holds it."""
+        bb = self.render_backbuffer
+        out = np.empty((bb.height, bb.width, 4), np.float32 if bb.format == N.OUT_RGBA32F else np.float16)
+        N.check(self._h, N.lib().vk_frame_readback(self._h, frame_id, out.ctypes.data, out.strides[0]))
+        return out
+
+    def capture_frame_of(self, frame_id: int):
+        """vk_frame_capture: capture_frame of that frame's presented Rgba8 image."""
+        dims = ImageDimentions.new(self.width, self.height, 256)
+        buf = np.zeros(dims.linear_size(), np.uint8)
+        N.check(self._h, N.lib().vk_frame_capture(self._h, frame_id, buf.ctypes.data, buf.size, None, None, None))
+        return buf.tobytes(), dims
+
+    def frame_info(self, frame_id: int) -> dict:
+        bb, r8, done = C.c_void_p(), C.c_void_p(), C.c_int()
+        N.check(self._h, N.lib().vk_frame_info(self._h, frame_id, C.byref(bb), C.byref(r8), C.byref(done)))
+        return {"backbuffer": bb.value, "rgba8": r8.value, "complete": bool(done.value)}
 
     def set_root_skip(self, k: int):
         """vk_partition_root_skip: rank 0 sits out every k-th round of the tile deal (0: never)."""
@@ -404,17 +444,25 @@ class Demo:
 
 
 def run_headless(demo_cls, frames: int = 1, camera: Camera | None = None, width: int = 1280, height: int = 720,
-                 backbuffer: tuple | None = None, out_format: int = N.OUT_RGBA16F, device: int = 0):
+                 backbuffer: tuple | None = None, out_format: int = N.OUT_RGBA16F, device: int = 0, in_flight: int = 1, on_frame=None):
     """`run::<D>` (src/lib.rs:45-208) without the window: N frames of
-    Context.update -> Demo.update -> Demo.render, then returns (ctx, demo)."""
+    Context.update -> Demo.update -> Demo.render, then returns (ctx, demo).
+    in_flight > 1: the loop runs up to that many frames ahead of the GPU, as the reference's queue does (src/lib.rs:178-194), every
+    frame on a surface of its own; on_frame(ctx, frame_id), if given, is called after each frame has been submitted."""
     ctx = Context(width, height, camera, device=device, backbuffer=backbuffer, out_format=out_format)
+    if in_flight > 1:
+        ctx.frames_in_flight(in_flight)
     fc = FrameCounter()
     demo = demo_cls.init(ctx)
     for _ in range(frames):
         ctx.update(fc)
         demo.update(ctx)
         fc.record()
+        fid = ctx.frame_begin()
         demo.render(ctx)
         ctx.render()  # src/lib.rs:178-182: demo.render, then context.render (present pass)
+        ctx.frame_end()
+        if on_frame is not None:
+            on_frame(ctx, fid)
     ctx.sync()
     return ctx, demo

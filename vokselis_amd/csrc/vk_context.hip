@@ -16,6 +16,71 @@ using namespace vk;
 
 thread_local std::string g_create_err;
 
+// ---- frame slots (frames in flight) ------------------------------------------------------------------------
+// The current slot's surface lives in the context's own fields; switching parks it and loads another slot's.
+static void frame_slot_switch(vk_ctx *ctx, uint32_t to) {
+    if (to == ctx->fif_cur) return;
+    vk_ctx::FrameSlot &a = ctx->fif[ctx->fif_cur], &b = ctx->fif[to];
+    a.backbuffer = ctx->backbuffer; a.steps = ctx->steps; a.rgba8 = ctx->rgba8; a.bgra8 = ctx->bgra8;
+    a.present_w = ctx->present_w; a.present_h = ctx->present_h;
+    ctx->backbuffer = b.backbuffer; ctx->steps = b.steps; ctx->rgba8 = b.rgba8; ctx->bgra8 = b.bgra8;
+    ctx->present_w = b.present_w; ctx->present_h = b.present_h;
+    b.backbuffer = nullptr; b.steps = nullptr; b.rgba8 = b.bgra8 = nullptr;
+    if (ctx->fif_k > 1) ctx->stream = b.stream;
+    ctx->fif_cur = to;
+}
+
+static vk_ctx::FrameSlot *frame_slot_of(vk_ctx *ctx, uint64_t id, uint32_t *index) {
+    if (id == 0) return nullptr;
+    for (uint32_t i = 0; i < ctx->fif_k; i++)
+        if (ctx->fif[i].id == id) { if (index) *index = i; return &ctx->fif[i]; }
+    return nullptr;
+}
+
+int frames_drain(vk_ctx *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->fif_k > 1)
+        for (uint32_t i = 0; i < ctx->fif_k; i++)
+            if (ctx->fif[i].stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->fif[i].stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+static void frame_slot_release(vk_ctx::FrameSlot &s, bool keep_stream) {  // a parked slot's device memory, event and stream
+    if (s.backbuffer) (void)hipFree(s.backbuffer);
+    if (s.steps) (void)hipFree(s.steps);
+    if (s.rgba8) (void)hipFree(s.rgba8);
+    if (s.bgra8) (void)hipFree(s.bgra8);
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.stream && !keep_stream) (void)hipStreamDestroy(s.stream);
+    s = vk_ctx::FrameSlot();
+}
+
+// (Re)allocate the CURRENT slot's backbuffer for the context's shape and clear it (HdrBackBuffer::new); its step image goes.
+static int surface_alloc_current(vk_ctx *ctx) {
+    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
+    if (ctx->steps) (void)hipFree(ctx->steps);
+    ctx->backbuffer = nullptr;
+    ctx->steps = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->backbuffer, (size_t)ctx->width * ctx->height * px_bytes(ctx->out_format)));
+    return vk_backbuffer_clear(ctx);
+}
+
+// Run `fn` with the frame's slot as the context's current surface (and stream), then restore the current one.
+template <class F>
+static int with_frame_slot(vk_ctx *ctx, uint64_t frame_id, const char *who, F fn) {
+    if (!ctx) return VK_ERR_INVALID;
+    uint32_t i = 0;
+    vk_ctx::FrameSlot *s = frame_slot_of(ctx, frame_id, &i);
+    if (!s) return fail(ctx, VK_ERR_INVALID, std::string(who) + (frame_id == 0 || frame_id > ctx->fif_last_id ? ": no such frame" : ": that frame's slot has been taken by a later frame"));
+    if (!s->ended) return fail(ctx, VK_ERR_INVALID, std::string(who) + ": that frame is still open (vk_frame_end first)");
+    const uint32_t cur = ctx->fif_cur;
+    frame_slot_switch(ctx, i);
+    const int rc = fn();
+    frame_slot_switch(ctx, cur);
+    return rc;
+}
+
 extern "C" {
 
 int vk_abi_version(void) { return VK_ABI_VERSION; }
@@ -65,7 +130,9 @@ int vk_ctx_create(int device_ordinal, vk_ctx **out) {
 int vk_ctx_destroy(vk_ctx *ctx) {
     if (!ctx) return VK_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)frames_drain(ctx);
+    frame_slot_switch(ctx, 0);  // slot 0 runs on own_stream (destroyed below); its surface is in the fields freed below
+    for (uint32_t i = 0; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], i == 0);
     comm_release(ctx);
     free_volume(ctx);
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
@@ -79,6 +146,7 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     for (auto &b : ctx->batch) { if (b.d) (void)hipFree(b.d); if (b.h) (void)hipHostFree(b.h); if (b.ev) (void)hipEventDestroy(b.ev); }
     for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
     for (hipEvent_t e : ctx->ring_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->ring_guard_ev) (void)hipEventDestroy(ctx->ring_guard_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -88,6 +156,7 @@ int vk_ctx_destroy(vk_ctx *ctx) {
 
 int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream) {
     if (!ctx) return VK_ERR_INVALID;
+    if (ctx->fif_k > 1) return fail(ctx, VK_ERR_INVALID, "vk_ctx_set_stream: a context with frames in flight runs its slots on streams of its own");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return VK_OK;
@@ -95,9 +164,7 @@ int vk_ctx_set_stream(vk_ctx *ctx, void *hip_stream) {
 
 int vk_ctx_sync(vk_ctx *ctx) {
     if (!ctx) return VK_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return VK_OK;
+    return frames_drain(ctx);
 }
 
 int vk_device_info(vk_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *arch_is_gfx950,
@@ -133,22 +200,136 @@ int vk_backbuffer_resize(vk_ctx *ctx, uint32_t width, uint32_t height, int out_f
     if (!ctx) return VK_ERR_INVALID;
     if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, VK_ERR_INVALID, "backbuffer size must be in [1, 32768]");
     if (out_format != VK_OUT_RGBA32F && out_format != VK_OUT_RGBA16F) return fail(ctx, VK_ERR_INVALID, "unknown output format");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->fif_open) return fail(ctx, VK_ERR_INVALID, "vk_backbuffer_resize: a frame is open (vk_frame_end first)");
+    int drc = frames_drain(ctx);
+    if (drc) return drc;
     for (auto &b : ctx->batch) b.id = 0;  // batch ids held by the caller named tiles of the old shape
     ctx->batch_key.clear();
     for (auto &r : ctx->batch_retired) { (void)hipFree(r.first); (void)hipHostFree(r.second); }
     ctx->batch_retired.clear();
-    if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
-    if (ctx->steps) (void)hipFree(ctx->steps);
-    ctx->backbuffer = nullptr;
-    ctx->steps = nullptr;
-    ctx->width = ctx->height = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->backbuffer, (size_t)width * height * px_bytes(out_format)));
     ctx->width = width;
     ctx->height = height;
     ctx->out_format = out_format;
-    return vk_backbuffer_clear(ctx);
+    // every slot of the ring takes the new shape; the frames they held are gone
+    const uint32_t cur = ctx->fif_cur;
+    int rc = VK_OK;
+    for (uint32_t i = 0; i < ctx->fif_k && rc == VK_OK; i++) {
+        frame_slot_switch(ctx, i);
+        ctx->fif[i].id = 0; ctx->fif[i].ended = false;
+        rc = surface_alloc_current(ctx);
+    }
+    frame_slot_switch(ctx, cur);
+    if (rc != VK_OK) { ctx->width = ctx->height = 0; return rc; }
+    return VK_OK;
+}
+
+// ---- frames in flight ------------------------------------------------------------------------------------
+// (include/vokselis_hip.h: the reference's queue runs ahead of the GPU, src/lib.rs:178-194; a swapchain bounds how far)
+
+int vk_ctx_frames_in_flight(vk_ctx *ctx, uint32_t k) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (k == 0 || k > VK_MAX_FRAMES_IN_FLIGHT) return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: k must be in [1, " + std::to_string(VK_MAX_FRAMES_IN_FLIGHT) + "]");
+    if (ctx->fif_open) return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: a frame is open (vk_frame_end first)");
+    if (k > 1 && ctx->stream != ctx->own_stream && ctx->fif_k == 1)
+        return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: the context runs on a caller's stream (vk_ctx_set_stream(ctx, NULL) first)");
+    int drc = frames_drain(ctx);
+    if (drc) return drc;
+    frame_slot_switch(ctx, 0);
+    ctx->stream = ctx->fif_k > 1 ? ctx->own_stream : ctx->stream;  // (slot 0 of a ring runs on own_stream)
+    for (uint32_t i = 0; i < VK_MAX_FRAMES_IN_FLIGHT; i++) { ctx->fif[i].id = 0; ctx->fif[i].ended = false; }
+    ctx->fif_seq = 0;
+    for (int i = 0; i < 16; i++) { ctx->ring_use_stream[i] = nullptr; ctx->ring_use_frame[i] = 0; }  // (drained: no reader is left)
+    for (uint32_t i = k; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], false);  // a smaller ring
+    if (k == 1) {
+        ctx->fif[0].stream = nullptr;  // one slot: on whatever stream the context runs on
+        ctx->fif_k = 1;
+        return VK_OK;
+    }
+    ctx->fif[0].stream = ctx->own_stream;
+    const uint32_t old_k = ctx->fif_k;
+    ctx->fif_k = k;  // (frame_slot_switch moves streams once the ring has more than one slot)
+    int rc = VK_OK;
+    for (uint32_t i = 1; i < k && rc == VK_OK; i++) {
+        vk_ctx::FrameSlot &s = ctx->fif[i];
+        if (!s.stream) {
+            hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { rc = fail(ctx, VK_ERR_HIP, std::string("vk_ctx_frames_in_flight: hipStreamCreate: ") + hipGetErrorString(e)); break; }
+        }
+        if (i >= old_k && ctx->width) {  // a new slot takes the backbuffer's current shape, cleared
+            frame_slot_switch(ctx, i);
+            rc = surface_alloc_current(ctx);
+            frame_slot_switch(ctx, 0);
+        }
+    }
+    if (rc != VK_OK) {  // back to one slot: never a ring with a slot that has no surface
+        (void)frames_drain(ctx);
+        for (uint32_t i = 1; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], false);
+        ctx->fif[0].stream = nullptr;
+        ctx->fif_k = 1;
+        return rc;
+    }
+    return frames_drain(ctx);  // (the clears)
+}
+
+int vk_frame_begin(vk_ctx *ctx, uint64_t *frame_id) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (ctx->fif_open) return fail(ctx, VK_ERR_INVALID, "vk_frame_begin: the previous frame is still open (vk_frame_end first)");
+    if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "vk_frame_begin: no backbuffer (vk_backbuffer_resize)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t slot = (uint32_t)(ctx->fif_seq % ctx->fif_k);
+    vk_ctx::FrameSlot &s = ctx->fif[slot];
+    // the swapchain's back-pressure (Surface::get_current_texture, src/context.rs:252): the frame that used this slot k frames ago has to be
+    // through before the slot is written again.  This is also what bounds how far launches lag behind the host (the tile-order ring of
+    // vk_order.hip holds 16 cameras: with at most VK_MAX_FRAMES_IN_FLIGHT frames in flight no slot of it is rewritten under a running launch).
+    // One slot: its frames follow one another on one stream, whose order alone protects the surface -- no wait (ABI 4's behaviour).
+    if (ctx->fif_k > 1 && s.id != 0 && s.ended) HIP_TRY(ctx, hipEventSynchronize(s.done));
+    if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    frame_slot_switch(ctx, slot);
+    ctx->fif_seq++;
+    s.id = ++ctx->fif_last_id;
+    s.ended = false;
+    ctx->fif_open = true;
+    if (frame_id) *frame_id = s.id;
+    return VK_OK;
+}
+
+int vk_frame_end(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (!ctx->fif_open) return fail(ctx, VK_ERR_INVALID, "vk_frame_end without vk_frame_begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    vk_ctx::FrameSlot &s = ctx->fif[ctx->fif_cur];
+    HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+    s.ended = true;
+    ctx->fif_open = false;
+    return VK_OK;
+}
+
+int vk_frame_wait(vk_ctx *ctx, uint64_t frame_id) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (frame_id == 0 || frame_id > ctx->fif_last_id) return fail(ctx, VK_ERR_INVALID, "vk_frame_wait: no such frame");
+    vk_ctx::FrameSlot *s = frame_slot_of(ctx, frame_id, nullptr);
+    if (!s) return VK_OK;  // its slot has been taken again: vk_frame_begin waited for it then
+    if (!s->ended) return fail(ctx, VK_ERR_INVALID, "vk_frame_wait: that frame is still open (vk_frame_end first)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(s->done));
+    return VK_OK;
+}
+
+int vk_frame_readback(vk_ctx *ctx, uint64_t frame_id, void *dst, size_t row_pitch_bytes) {
+    return with_frame_slot(ctx, frame_id, "vk_frame_readback", [&] { return vk_readback(ctx, dst, row_pitch_bytes); });
+}
+
+int vk_frame_capture(vk_ctx *ctx, uint64_t frame_id, void *dst, size_t dst_bytes, uint32_t *out_width, uint32_t *out_height, uint32_t *out_padded_bytes_per_row) {
+    return with_frame_slot(ctx, frame_id, "vk_frame_capture", [&] { return vk_capture_frame(ctx, dst, dst_bytes, out_width, out_height, out_padded_bytes_per_row); });
+}
+
+int vk_frame_info(vk_ctx *ctx, uint64_t frame_id, void **backbuffer, void **rgba8, int *complete) {
+    return with_frame_slot(ctx, frame_id, "vk_frame_info", [&] {
+        if (backbuffer) *backbuffer = ctx->backbuffer;
+        if (rgba8) *rgba8 = ctx->rgba8;
+        if (complete) *complete = hipEventQuery(ctx->fif[ctx->fif_cur].done) == hipSuccess ? 1 : 0;
+        return (int)VK_OK;
+    });
 }
 
 int vk_backbuffer_info(vk_ctx *ctx, uint32_t *width, uint32_t *height, int *out_format, void **device_ptr) {

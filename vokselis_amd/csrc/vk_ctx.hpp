@@ -81,6 +81,9 @@ struct vk_ctx {
     bool ring_done[16] = {};
     uint32_t ring_active[16] = {};   // order_active of the slot
     uint32_t order_seq = 0;          // order changes so far; change e lives in slot e % 16
+    hipStream_t ring_use_stream[16] = {};  // frames in flight: the stream of the slot's last reader ...
+    uint64_t ring_use_frame[16] = {};      // ... and the frame it belonged to (0: launched outside vk_frame_begin / vk_frame_end)
+    hipEvent_t ring_guard_ev = nullptr;
 
     // batched launches (vk_render_batch): per-batch tables {FrameDesc[B], order[B][n_tiles], pos[B][n_tiles]} in a small
     // ring of device slots fed from pinned staging; a slot is rewritten only after the last kernel that read it
@@ -119,6 +122,25 @@ struct vk_ctx {
     uint32_t *rgba8 = nullptr, *bgra8 = nullptr;
     uint32_t present_w = 0, present_h = 0;
 
+    // Frames in flight (vk_ctx_frames_in_flight; vk_context.hip).  A slot owns a frame's surface: backbuffer, step image,
+    // present targets, the stream its work runs on and the event that marks its end.  The CURRENT slot's surface lives in the
+    // fields above (backbuffer, steps, rgba8, bgra8, present_w/h, stream) -- every other translation unit keeps addressing
+    // those -- and is parked in its FrameSlot while another slot is current (frame_slot_switch).  fif_k == 1: one slot, on
+    // whatever stream the context runs on.
+    struct FrameSlot {
+        void *backbuffer = nullptr;
+        uint32_t *steps = nullptr, *rgba8 = nullptr, *bgra8 = nullptr;
+        uint32_t present_w = 0, present_h = 0;
+        hipStream_t stream = nullptr;  // fif_k > 1: slot 0 = own_stream, the others created with the ring
+        hipEvent_t done = nullptr;     // recorded by vk_frame_end
+        uint64_t id = 0;               // the frame the slot holds (0: none)
+        bool ended = false;            // ... and whether vk_frame_end has recorded `done` for it
+    } fif[VK_MAX_FRAMES_IN_FLIGHT];
+    uint32_t fif_k = 1, fif_cur = 0;
+    uint64_t fif_seq = 0;       // frames begun since the ring was sized: frame number n takes slot n % fif_k
+    uint64_t fif_last_id = 0;   // ids handed out so far (never reused by a context)
+    bool fif_open = false;      // between vk_frame_begin and vk_frame_end
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_open = false, timing_done = false;
 
@@ -151,6 +173,7 @@ inline size_t px_bytes(int fmt) { return fmt == VK_OUT_RGBA16F ? 8 : 16; }
 inline size_t wire_px_bytes(int fmt, int wire) { return wire == VK_WIRE_RGB ? px_bytes(fmt) / 4 * 3 : px_bytes(fmt); }
 
 // ---- shared between translation units --------------------------------------------------------------------
+int frames_drain(vk_ctx *ctx);   // vk_context.hip: wait for the work of every frame slot (one stream when fif_k == 1)
 void free_volume(vk_ctx *ctx);   // vk_volume.hip
 void comm_release(vk_ctx *ctx);  // vk_comm.hip
 

@@ -177,6 +177,14 @@ static void compute_tile_order(const vk_ctx *ctx, const float *cam, int mode, in
     compute_tile_order_raw(ctx, cam, mode, ox, oy, rw, rh, ts, order.data(), order_pos.data(), order_active, (int)ctx->order_rays);
 }
 
+// Every caller of tile_order_update goes on to launch a reader of the current slot on ctx->stream: who that is, for the day
+// the ring comes round to the slot again.
+static void order_note_use(vk_ctx *ctx) {
+    if (ctx->ring_slot < 0) return;
+    ctx->ring_use_stream[ctx->ring_slot] = ctx->stream;
+    ctx->ring_use_frame[ctx->ring_slot] = ctx->fif_open ? ctx->fif[ctx->fif_cur].id : 0;
+}
+
 int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts) {
     const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
     const size_t n = (size_t)tx * ty;
@@ -184,7 +192,7 @@ int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw
     std::memcpy(key.data(), ctx->camera, 144);
     const uint32_t kk[10] = {(uint32_t)mode, (uint32_t)ox, (uint32_t)oy, rw, rh, ts, ctx->width, ctx->height, ctx->nx ^ (ctx->ny << 10) ^ (ctx->nz << 20), 0};
     std::memcpy(key.data() + 144, kk, 40);
-    if (key == ctx->order_key && ctx->order.size() == n) return VK_OK;
+    if (key == ctx->order_key && ctx->order.size() == n) { order_note_use(ctx); return VK_OK; }
     compute_tile_order(ctx, ctx->camera, mode, ox, oy, rw, rh, ts, ctx->order, ctx->order_pos, ctx->order_active);
     const uint32_t n_active = ctx->order_active;
     constexpr int kOrderRing = 16;
@@ -201,12 +209,32 @@ int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw
     const size_t cap = ctx->d_order_cap;
     const int slot = (int)(++ctx->order_seq % (uint32_t)kOrderRing);
     // Waiting on the slot's previous upload (kOrderRing cameras ago) makes the pinned staging safe to rewrite.  The
-    // device slot itself is safe to overwrite because a context works on ONE stream: the kernels that read the slot
-    // kOrderRing cameras ago were enqueued on ctx->stream before this copy (vk_ctx_set_stream drains the old stream
-    // first), so the copy is stream-ordered after them.  (Frames in flight are batched launches now, vk_render_batch,
-    // which carry their own tables.)
+    // device slot itself is safe to overwrite: on ONE stream the kernels that read the slot kOrderRing cameras ago were
+    // enqueued before this copy (vk_ctx_set_stream drains the old stream first), so the copy is stream-ordered after them;
+    // with frames in flight (several streams) the slot's last reader may belong to a frame on ANOTHER stream -- a frame that
+    // draws its tiles one launch at a time (the xor example's 3 x 6 tile loop) goes round the ring inside every frame: this
+    // stream then waits for that frame's end (nothing to wait for when vk_frame_begin has since retaken its surface: it
+    // waited on the host then).
     if (ctx->ring_ev[slot]) HIP_TRY(ctx, hipEventSynchronize(ctx->ring_ev[slot]));
     else HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ring_ev[slot], hipEventDisableTiming));
+    if (ctx->fif_k > 1 && ctx->ring_use_stream[slot] && ctx->ring_use_stream[slot] != ctx->stream) {
+        bool ordered = false;
+        const uint64_t f = ctx->ring_use_frame[slot];
+        if (f != 0) {
+            const vk_ctx::FrameSlot *fs = nullptr;
+            for (uint32_t i = 0; i < ctx->fif_k; i++) if (ctx->fif[i].id == f) fs = &ctx->fif[i];
+            if (!fs) ordered = true;
+            else if (fs->ended) {
+                if (hipEventQuery(fs->done) != hipSuccess) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, fs->done, 0));
+                ordered = true;
+            }
+        }
+        if (!ordered) {  // a reader outside any frame: order this stream after everything its stream has been given so far
+            if (!ctx->ring_guard_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ring_guard_ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ctx->ring_guard_ev, ctx->ring_use_stream[slot]));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_guard_ev, 0));
+        }
+    }
     uint32_t *hs = ctx->h_ring + (size_t)slot * 2 * cap, *ds = ctx->d_ring + (size_t)slot * 2 * cap;
     std::memcpy(hs, ctx->order.data(), n * sizeof(uint32_t));
     std::memcpy(hs + cap, ctx->order_pos.data(), n * sizeof(uint32_t));
@@ -219,6 +247,7 @@ int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw
     ctx->d_order = ds;
     ctx->d_order_pos = ds + cap;
     ctx->order_key = key;
+    order_note_use(ctx);
     return VK_OK;
 }
 

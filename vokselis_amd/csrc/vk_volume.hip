@@ -63,6 +63,9 @@ struct DenseSource {
 };
 
 static int commit_volume(vk_ctx *ctx, VolBuild &nb) {
+    // frames in flight on other slots' streams still read the previous volume, and the next ones must find this one built
+    // (the build ran on the current slot's stream): drain every slot.  One slot: stream order does it, as before.
+    if (ctx->fif_k > 1) { int drc = frames_drain(ctx); if (drc) return drc; }
     free_volume(ctx);
     for (auto &b : ctx->batch) b.id = 0;  // batches dealt for the previous volume are no longer un-tiled
     ctx->batch_key.clear();

@@ -4,6 +4,7 @@
 //          [--f32] [--dump-rgba file] [--dump-steps file]   parity surface (rgba32f) + per-pixel trip counts, raw
 //          [--gpus N] [--batch B] [--peer-direct]            the frame's tiles over N GPUs of this node (vk_group_*); --peer-direct: the GPUs
 //                                                            store into GPU 0's frames themselves instead of gather + un-tile
+//          [--in-flight K] [--orbit]                          K frames in flight (vk_ctx_frames_in_flight); --orbit: the camera turns by 2 pi / 1024 every frame
 //          [--camera-blobs orbits.txt out.bin]              no GPU: one 144-byte CameraUniform per "zoom pitch yaw tx ty tz aspect" line
 #include <cstdio>
 #include <algorithm>
@@ -16,6 +17,7 @@ using namespace vokselis;
 
 static std::string g_raw;
 static float g_dt = 1.0f;
+static bool g_orbit = false;
 
 struct Bonsai : Demo {
     std::unique_ptr<VolumeTexture> volume_texture;
@@ -27,6 +29,7 @@ struct Bonsai : Demo {
         self->pipeline = RaycastPipeline{VK_MODE_NAIVE_TRILINEAR, g_dt, 0};
         return self;
     }
+    void update(Context &ctx) override { if (g_orbit) ctx.camera.add_yaw(6.28318f / 1024.f); }  // (a mouse drag: src/lib.rs:166-171)
     void render(Context &ctx) override { pipeline.record(ctx); }  // examples/bonsai/main.rs:27-57
 };
 
@@ -102,7 +105,7 @@ static int dump_camera_blobs(const std::string &in, const std::string &out) {
 }
 
 int main(int argc, char **argv) {
-    uint32_t frames = 100, w = 1280, h = 720, batch = 8;
+    uint32_t frames = 100, w = 1280, h = 720, batch = 8, in_flight = 1;
     int gpus = 0;
     bool f32 = false, peer_direct = false;
     std::string ppm, dump_rgba, dump_steps;
@@ -119,6 +122,8 @@ int main(int argc, char **argv) {
         else if (a == "--dump-steps") dump_steps = next();
         else if (a == "--gpus") gpus = std::atoi(next());
         else if (a == "--peer-direct") peer_direct = true;
+        else if (a == "--in-flight") in_flight = (uint32_t)std::max(1, std::atoi(next()));
+        else if (a == "--orbit") g_orbit = true;
         else if (a == "--batch") batch = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--camera-blobs") { std::string in = next(); return dump_camera_blobs(in, next()); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -132,8 +137,8 @@ int main(int argc, char **argv) {
         Context ctx(w, h, &camera, 0, bb);
         std::printf("%s\n", ctx.get_info().c_str());
         double ms = 0;
-        auto demo = run_headless<Bonsai>(ctx, frames, &ms);
-        std::printf("Avg frame time %.4fms over %u frames\n", ms, frames);  // src/utils/frame_counter.rs:23-24
+        auto demo = run_headless<Bonsai>(ctx, frames, &ms, in_flight);
+        std::printf("Avg frame time %.4fms over %u frames (%u in flight)\n", ms, frames, in_flight);  // src/utils/frame_counter.rs:23-24
         auto shot = ctx.capture_frame();
         uint64_t sum = 0;
         for (uint8_t b : shot.first) sum += b;

@@ -227,6 +227,18 @@ class Context {
     }
     void resize(uint32_t w, uint32_t h) { width = w; height = h; camera.set_aspect(w, h); }  // context.rs:238-249
     void sync() { check(ctx_, vk_ctx_sync(ctx_)); }
+    // Frames in flight: the reference's queue runs ahead of the GPU (src/lib.rs:178-194), bounded by the swapchain
+    // (get_current_texture, src/context.rs:252).  k surfaces, each on a stream of its own; 1 = one surface (the default).
+    void frames_in_flight(uint32_t k) { check(ctx_, vk_ctx_frames_in_flight(ctx_, k)); }
+    uint64_t frame_begin() { uint64_t id = 0; check(ctx_, vk_frame_begin(ctx_, &id)); return id; }  // the acquire
+    void frame_end() { check(ctx_, vk_frame_end(ctx_)); }                                          // submit + present
+    void frame_wait(uint64_t id) { check(ctx_, vk_frame_wait(ctx_, id)); }
+    std::pair<std::vector<uint8_t>, ImageDimentions> capture_frame_of(uint64_t id) {
+        ImageDimentions dims(width, height, 256);
+        std::vector<uint8_t> out(dims.linear_size(), 0);
+        check(ctx_, vk_frame_capture(ctx_, id, out.data(), out.size(), nullptr, nullptr, nullptr));
+        return {out, dims};
+    }
     std::string get_info() const {
         char name[256]; int cus = 0, is950 = 0; size_t mem = 0;
         check(ctx_, vk_device_info(ctx_, name, sizeof name, &cus, &is950, &mem));
@@ -326,18 +338,23 @@ struct Demo {
     virtual void render(Context &) {}
 };
 
-// run::<D> (src/lib.rs:45-208) without the window: Context::update -> Demo::update -> Demo::render
+// run::<D> (src/lib.rs:45-208) without the window: Context::update -> Demo::update -> Demo::render.
+// in_flight > 1: the loop runs up to that many frames ahead of the GPU, every frame on a surface of its own.
 template <class D>
-std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_frame_ms = nullptr) {
+std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_frame_ms = nullptr, uint32_t in_flight = 1) {
     FrameCounter fc;
+    if (in_flight > 1) ctx.frames_in_flight(in_flight);
     std::unique_ptr<D> demo = D::init(ctx);
+    ctx.sync();  // (volume set-up is not frame time)
     auto t0 = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < frames; i++) {
         ctx.update(fc);
         demo->update(ctx);
         fc.record();
+        ctx.frame_begin();
         demo->render(ctx);
         ctx.render();  // src/lib.rs:178-182: demo.render, then context.render (present)
+        ctx.frame_end();
     }
     ctx.sync();
     if (mean_frame_ms) *mean_frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames ? frames : 1);
