@@ -79,12 +79,26 @@ enum vk_render_flags {
     VK_RENDER_DEBUG_FALLBACK = 32, /* with COUNT, VK_LAYOUT_STAGED: vk_readback_steps returns the steps whose taps came from global memory */
     VK_RENDER_PROBE_ALWAYS = 64, /* skip kernels: look the distance map up on every trip (no adaptive dense stretches): S_sampled is then
                                    exactly the number of steps that can contribute; the frame is the same either way */
-    VK_RENDER_FAST_WALK = 128 /* TOLERANCE MODE of the skip kernels: a run of exactly transparent steps advances the ray in closed form
+    VK_RENDER_FAST_WALK = 128, /* TOLERANCE MODE of the skip kernels: a run of exactly transparent steps advances the ray in closed form
                                  (one fma per accumulator) instead of by the reference loop's own sequence of rounded additions
                                  (raycast_naive.wgsl:101,118).  t stays exact; the sample positions part from the default, bit-exact mode's
                                  by ~2e-4 cell where a coordinate crosses a power of two inside a skipped run: 99.99 % of C2's pixels
                                  within 1.04e-4, a handful per frame (0.004 %) whose alpha >= 0.95 early-out flips up to 2e-2 off.
                                  19 % faster on C2.  Ignored by kernels that do not skip. */
+    /* ABI 5 -- the present pass fused into the raycast pass's epilogue (vk_render only).  When the window has the backbuffer's size,
+     * Context::render's present (src/context.rs:251-297, shaders/present.wgsl:111-119) reads each texel once, at its centre: the
+     * lane that holds the finished pixel applies ACESFilm + linear_to_srgb itself and writes the context's Rgba8Unorm target (what
+     * vk_capture_frame reads) -- no second launch, and the 8-16 bytes per pixel the present pass would read back are never
+     * fetched.  A tile-by-tile frame (examples/xor/main.rs:235-254) presents every tile it renders.
+     *   VK_RENDER_PRESENT       also write the presented pixel (the target is sized to the backbuffer, as by vk_present(w, h))
+     *   VK_RENDER_PRESENT_BGRA  ... and the Bgra8Unorm surface copy (vk_present's also_bgra); implies VK_RENDER_PRESENT
+     *   VK_RENDER_PRESENT_ONLY  ... and do NOT store the HDR pixel: the backbuffer keeps what it held; implies VK_RENDER_PRESENT
+     * Equal to vk_render followed by vk_present(width, height) on every pixel that pass samples at a texel centre; its f32 pixel
+     * coordinates put a few per cent of the samples (52 columns and 43 rows of 1920 x 1080) ~1e-7 of a texel off centre, and there the
+     * two may differ by one 8-bit step (a hardware sampler's fixed-point weights read the centre there too). */
+    VK_RENDER_PRESENT = 256,
+    VK_RENDER_PRESENT_BGRA = 512,
+    VK_RENDER_PRESENT_ONLY = 1024
 };
 
 /* ---- context: replaces Context::new device/queue setup, src/context.rs:71-181 ---------- */

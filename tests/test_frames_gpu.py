@@ -219,3 +219,114 @@ def test_run_headless_in_flight(V):
         finally:
             ctx.close()
     assert (shots[1][0].view(np.uint8) == shots[3][0].view(np.uint8)).all() and shots[1][1] == shots[3][1]
+
+
+# ---- present fused into the raycast pass's epilogue (VK_RENDER_PRESENT*) ------------------------------------------------------
+
+
+def _shot(ctx, fid=None):
+    buf, dims = ctx.capture_frame() if fid is None else ctx.capture_frame_of(fid)
+    rows = np.frombuffer(buf, np.uint8).reshape(dims.height, dims.padded_bytes_per_row)
+    return rows[:, :dims.unpadded_bytes_per_row].reshape(dims.height, dims.width, 4).copy()
+
+
+def _centred(n):
+    """Columns (rows) of an n-wide present at the backbuffer's own size whose f32 sample coordinate (present.wgsl's uv * size - 0.5, as
+    vk_present and the oracle compute it) is exactly the texel's centre."""
+    x = np.arange(n, dtype=np.float32)
+    uv = (x + np.float32(0.5)) / np.float32(n)
+    u = (uv.astype(np.float64) * np.float64(n) - 0.5).astype(np.float32)  # fmaf(uv, n, -0.5): the product is exact in binary64
+    return (np.floor(u) == x) & (u - np.floor(u) == 0)
+
+
+def _fused_cases(V):
+    naive = lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3)
+    return [
+        # (name, w, h, volume, mode, dt, camera, tiles or None)
+        ("bonsai 720p", 1280, 720, naive, V.MODE_NAIVE_TRILINEAR, 1.0, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
+        ("bonsai 480x270", 480, 270, naive, V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
+        ("staged", 320, 180, lambda c: V.VolumeTexture.generate_fog(c, (96,) * 3, layout=V.LAYOUT_STAGED, dense_core=True), V.MODE_NAIVE_TRILINEAR, 0.5,
+         (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
+        ("xor single", 1280, 720, lambda c: V.VolumeTexture.generate_xor(c, (128,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)), None),
+        ("xor tiles", 1280, 720, lambda c: V.VolumeTexture.generate_xor(c, (128,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)),
+         [(x * 256, y * 256, 256, 256) for y in range(3) for x in range(6)]),
+        ("procedural", 160, 90, lambda c: None, V.MODE_PROCEDURAL, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)), None),
+    ]
+
+
+def test_present_fused_equals_render_then_present(V, O):
+    """VK_RENDER_PRESENT: the pass's own lanes apply ACES + sRGB and write the Rgba8 (and Bgra8) targets.  Against vk_render followed by
+    vk_present at the backbuffer's size: the HDR backbuffer bitwise; the presented image equal on every pixel vk_present samples at a
+    texel centre, within one 8-bit step on the few whose f32 coordinate lands ~1e-7 off centre; within one step of the oracle's present
+    everywhere.  VK_RENDER_PRESENT_ONLY leaves the backbuffer alone."""
+    for name, w, h, mkvol, mode, dt, cam, tiles in _fused_cases(V):
+        for fmt in (V.OUT_RGBA16F, V.OUT_RGBA32F):
+            ctx = V.Context(w, h, backbuffer=(w, h), out_format=fmt)
+            try:
+                mkvol(ctx)
+                z, p, y, t = cam
+                ctx.set_camera_blob(V.Camera(z, p, y, t, w / h).get_proj_view_matrix())
+
+                def draw(flags):
+                    pipe = V.RaycastPipeline(mode, dt_scale=dt, flags=flags)
+                    for tl in (tiles or [None]):
+                        pipe.record(ctx, tl)
+
+                draw(0)
+                ctx.render()  # vk_present(w, h)
+                bb0, two_pass = ctx.read_backbuffer(), _shot(ctx)
+                V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+                draw(V.RENDER_PRESENT | V.RENDER_PRESENT_BGRA)
+                bb1, fused = ctx.read_backbuffer(), _shot(ctx)
+                assert (bb1.view(np.uint8) == bb0.view(np.uint8)).all(), name
+                centre = _centred(h)[:, None] & _centred(w)[None, :]
+                d = np.abs(fused.astype(np.int32) - two_pass.astype(np.int32)).max(axis=2)
+                assert (d[centre[:d.shape[0], :d.shape[1]]] == 0).all(), (name, fmt)
+                assert d.max() <= 1, (name, fmt, d.max())
+                want = O.present(bb0.astype(np.float32), w, h)[:fused.shape[0], :fused.shape[1]].astype(np.int32)
+                do = np.abs(fused.astype(np.int32) - want)
+                assert do.max() <= 1 and (do == 0).mean() > 0.995, (name, fmt, do.max(), (do == 0).mean())
+                assert (fused[..., 3] == 255).all() and fused[..., :3].max() > 30
+                # PRESENT_ONLY: the backbuffer keeps what it held
+                V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
+                cleared = ctx.read_backbuffer()
+                draw(V.RENDER_PRESENT_ONLY)
+                assert (ctx.read_backbuffer().view(np.uint8) == cleared.view(np.uint8)).all(), name
+                assert (_shot(ctx) == fused).all(), name
+            finally:
+                ctx.close()
+
+
+def test_present_fused_misuse_and_frames_in_flight(V):
+    import torch
+
+    w, h = 480, 270
+    ctx = bonsai_ctx(V, 3, out=V.OUT_RGBA16F)
+    try:
+        cams = orbit(V, 5)
+        ref = []
+        for cb in cams:  # two passes, one surface at a time
+            ctx.set_camera_blob(cb)
+            fid = ctx.frame_begin()
+            V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT).record(ctx)
+            ctx.render()
+            ctx.frame_end()
+            ref.append(_shot(ctx, fid))
+        ids = []
+        for cb in cams:  # fused, three in flight
+            ctx.set_camera_blob(cb)
+            ids.append(ctx.frame_begin())
+            V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT, flags=V.RENDER_PRESENT).record(ctx)
+            ctx.frame_end()
+        for j in (2, 3, 4):
+            d = np.abs(_shot(ctx, ids[j]).astype(np.int32) - ref[j].astype(np.int32))
+            assert d.max() <= 1 and (d == 0).mean() > 0.999, j
+        # compact / batched passes have no presented image
+        buf = torch.empty((64 * 64 * 64 * 8,), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(V.VokselisError):
+            V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT, flags=V.RENDER_PRESENT).record_partition(ctx, 64, 0, 1, buf.data_ptr())
+        with pytest.raises(V.VokselisError):
+            V.render_batch(ctx, V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT, flags=V.RENDER_PRESENT_ONLY), [cams[0]], buf.data_ptr())
+    finally:
+        ctx.close()

@@ -1,7 +1,7 @@
 """Frames in flight in a few seconds: ms per frame of the one-vk_render-per-frame surface, every frame a new orbit camera, on one
 surface / one stream (today's vk_render loop) and on rings of K = 1..4 surfaces (vk_ctx_frames_in_flight), for C2 (bonsai stand-in
 256^3, 1080p, dt_scale 0.5) and the xor example's own frame (256^3 pair, 1280x720).  Wall time around N frames, best of three.
-usage: tools/fif_quick.py [--frames N] [--present]"""
+usage: tools/fif_quick.py [--frames N] [--present | --fused]   (--present: vk_present after every vk_render; --fused: VK_RENDER_PRESENT)"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ import vokselis_amd as V
 
 n = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
 present = "--present" in sys.argv
+fused = "--fused" in sys.argv
 
 
 def stream_of_frames(ctx, pipe, cams, frames_api):
@@ -39,7 +40,7 @@ def stream_of_frames(ctx, pipe, cams, frames_api):
     return best, host
 
 
-out = {"lib": os.environ.get("VK_LIB", "product"), "frames": n, "present": present}
+out = {"lib": os.environ.get("VK_LIB", "product"), "frames": n, "present": "fused" if fused else present}
 for name, (w, h), mk, mode, dt, cam0 in (
         ("c2", (1920, 1080), lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
         ("xor720p", (1280, 720), lambda c: V.VolumeTexture.generate_xor(c, (256,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))):
@@ -47,7 +48,7 @@ for name, (w, h), mk, mode, dt, cam0 in (
     mk(ctx)
     z, p, y, t = cam0
     cams = [V.Camera(z, p, y + 6.28318 * j / 1024, t, w / h).get_proj_view_matrix() for j in range(128)]
-    pipe = V.RaycastPipeline(mode, dt_scale=dt)
+    pipe = V.RaycastPipeline(mode, dt_scale=dt, flags=V.RENDER_PRESENT if fused else 0)
     ctx.set_camera_blob(cams[0])
     for _ in range(200):
         pipe.record(ctx)  # clocks

@@ -24,6 +24,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     if (!cameras || !out) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: NULL argument");
     if (n_frames == 0 || n_frames > VK_MAX_BATCH_FRAMES) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: 1..1024 frames per batch");
     if (flags & VK_RENDER_COUNT) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: the step counters describe one frame; count with vk_render");
+    if (flags & (VK_RENDER_PRESENT | VK_RENDER_PRESENT_BGRA | VK_RENDER_PRESENT_ONLY)) return fail(ctx, VK_ERR_INVALID, "vk_render_batch: the fused present belongs to the one-frame pass (vk_render)");
     // (compact == 0 with nranks > 1: this rank's tiles at their place in whole frames that live elsewhere -- the root's, over xGMI: vk_group_peer_direct)
     const float *cams = reinterpret_cast<const float *>(cameras);
     for (uint32_t i = 0; i < n_frames * 36u; i++)

@@ -111,6 +111,11 @@ struct LaunchDesc {
     float walk_cap;                // skip kernels: steps a walk may take in a trip in which other lanes sample (+inf: no cap)
     float walk_cap_all;            // ... and in a trip in which every lane walks
     uint32_t pair_walk_min;        // compute twin, record kernel: a run of records that cannot contribute is walked only if it is at least this many steps long
+    // Present fused into the pass's epilogue (VK_RENDER_PRESENT; single-frame, whole-pixel launches only): the lane that holds a pixel also
+    // writes its presented Rgba8 (and Bgra8) value at the same index -- the present pass at the backbuffer's own size (store_present).
+    uint32_t *present_rgba8;       // nullptr: no fused present
+    uint32_t *present_bgra8;       // optional surface copy
+    uint32_t present_only;         // != 0: the HDR pixel itself is not stored
 };
 
 // LaunchDesc::flags.  Policy and instrumentation switches of one launch, set by the host (vk_render.hip) and read by the kernels.
@@ -279,11 +284,54 @@ __device__ __forceinline__ void store_pixel(void *out, size_t idx, float r, floa
     }
 }
 
+// ---- present pass arithmetic (shaders/present.wgsl:23-35,111-119), shared by present_kernel (vk_post.hpp) and the fused epilogue ----
+__device__ __forceinline__ float aces_film(float x) {
+    float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
+    return fminf(fmaxf(num / den, 0.0f), 1.0f);
+}
+__device__ __forceinline__ float present_srgb(float c) {
+    float sel = ceilf(c - 0.0031308f);
+    float under = 12.92f * c;
+    float over = 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * 0.41666f) - 0.055f;
+    return sel > 0.0f ? over : under;  // mix(under, over, sel) with sel in {0, 1}
+}
+// (r, g, b, a) sampled from the backbuffer -> Rgba8Unorm / Bgra8Unorm words: ACESFilm + linear_to_srgb on the colour, round to 8 bits
+__device__ __forceinline__ void present_pack(const float px[4], uint32_t &rgba, uint32_t &bgra) {
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float v = px[k];
+        if (k < 3) v = present_srgb(aces_film(v));
+        c[k] = floorf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+    const uint32_t r = (uint32_t)c[0], g = (uint32_t)c[1], b = (uint32_t)c[2], al = (uint32_t)c[3];
+    rgba = r | (g << 8) | (b << 16) | (al << 24);
+    bgra = b | (g << 8) | (r << 16) | (al << 24);
+}
+// The fused present of one pixel: what present_kernel computes for a sample on the texel's centre -- weights (1, 0, 0, 0) -- from the value
+// the backbuffer holds (an rgba16f surface holds the RNE-rounded half: present what is stored, not what was computed).
+template <int OUT>
+__device__ __forceinline__ void store_present(const LaunchDesc &L, size_t idx, float r, float g, float b) {
+    float px[4] = {r, g, b, 1.0f};
+    if (OUT == OUT_RGBA16F) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) px[k] = (float)(_Float16)px[k];
+    }
+    uint32_t rgba, bgra;
+    present_pack(px, rgba, bgra);
+    L.present_rgba8[idx] = rgba;
+    if (L.present_bgra8) L.present_bgra8[idx] = bgra;
+}
+
 // A pixel of a launch: the full (r, g, b, 1) pixel, or -- compact == 2, the lean wire format of a partition -- (r, g) into the
 // record's first plane and b into its second.  Every pixel this path writes has alpha 1 (raycast_naive.wgsl:124,
 // raycast_compute.wgsl:143), and the tiles of a partition exist to be moved over xGMI: 6 bytes instead of 8 (rgba16f).
 template <int OUT>
 __device__ __forceinline__ void store_out(const LaunchDesc &L, const PixelMap &pm, float r, float g, float b) {
+    if (L.present_rgba8) {  // wave-uniform (the host sets it for compact == 0, one frame)
+        store_present<OUT>(L, pm.out_index, r, g, b);
+        if (L.present_only) return;
+    }
     if (L.compact != 2u) { store_pixel<OUT>(L.out, pm.out_index, r, g, b, 1.0f); return; }  // wave-uniform
     const size_t tt = (size_t)L.ts * L.ts;
     if (OUT == OUT_RGBA32F) {

@@ -185,6 +185,9 @@ void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode, int32
 int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts);
 int order_wait(vk_ctx *ctx);
 
+// vk_post.hip
+int present_targets(vk_ctx *ctx, uint32_t width, uint32_t height, bool also_bgra);
+
 // vk_render.hip
 int check_render(vk_ctx *ctx, int mode, const float *cam, float dt_scale, uint32_t ts, uint32_t rank, uint32_t nranks);
 int dispatch_march(vk_ctx *ctx, int mode, const vk::LaunchDesc &L_in, uint32_t flags, const float *reach_cam);

@@ -46,6 +46,23 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
     return VK_OK;
 }
 
+// The current surface's Rgba8 (and Bgra8) present targets at width x height (the rgb_texture of src/context.rs:59-60,246).
+int present_targets(vk_ctx *ctx, uint32_t width, uint32_t height, bool also_bgra) {
+    if (width == ctx->present_w && height == ctx->present_h && ctx->rgba8 && (!also_bgra || ctx->bgra8)) return VK_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->rgba8) (void)hipFree(ctx->rgba8);
+    if (ctx->bgra8) (void)hipFree(ctx->bgra8);
+    ctx->rgba8 = ctx->bgra8 = nullptr;
+    ctx->present_w = ctx->present_h = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->rgba8, (size_t)width * height * 4));
+    if (also_bgra) HIP_TRY(ctx, hipMalloc(&ctx->bgra8, (size_t)width * height * 4));
+    // (a tile-by-tile fused present fills it piecewise: what no tile covers reads as transparent black, never as stale memory)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->rgba8, 0, (size_t)width * height * 4, ctx->stream));
+    if (also_bgra) HIP_TRY(ctx, hipMemsetAsync(ctx->bgra8, 0, (size_t)width * height * 4, ctx->stream));
+    ctx->present_w = width; ctx->present_h = height;
+    return VK_OK;
+}
+
 extern "C" {
 
 int vk_backbuffer_clear(vk_ctx *ctx) {
@@ -111,16 +128,8 @@ int vk_present(vk_ctx *ctx, uint32_t width, uint32_t height, int also_bgra) {
     if (!ctx->backbuffer) return fail(ctx, VK_ERR_INVALID, "vk_present: no backbuffer");
     if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, VK_ERR_INVALID, "vk_present: size must be in [1, 32768]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (width != ctx->present_w || height != ctx->present_h || (also_bgra && !ctx->bgra8)) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->rgba8) (void)hipFree(ctx->rgba8);
-        if (ctx->bgra8) (void)hipFree(ctx->bgra8);
-        ctx->rgba8 = ctx->bgra8 = nullptr;
-        ctx->present_w = ctx->present_h = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->rgba8, (size_t)width * height * 4));
-        if (also_bgra) HIP_TRY(ctx, hipMalloc(&ctx->bgra8, (size_t)width * height * 4));
-        ctx->present_w = width; ctx->present_h = height;
-    }
+    int prc = present_targets(ctx, width, height, also_bgra != 0);
+    if (prc) return prc;
     const uint64_t n = (uint64_t)width * height;
     hipLaunchKernelGGL(present_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->backbuffer,
                        ctx->out_format == VK_OUT_RGBA16F ? OUT_RGBA16F : OUT_RGBA32F, ctx->width, ctx->height, width, height,

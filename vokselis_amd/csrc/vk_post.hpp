@@ -22,16 +22,6 @@ __device__ __forceinline__ float4 load_px(const void *bb, int fmt, size_t idx) {
     uint2 v = reinterpret_cast<const uint2 *>(bb)[idx];
     return make_float4(h2f(v.x & 0xffffu), h2f(v.x >> 16), h2f(v.y & 0xffffu), h2f(v.y >> 16));
 }
-__device__ __forceinline__ float aces_film(float x) {
-    float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
-    return fminf(fmaxf(num / den, 0.0f), 1.0f);
-}
-__device__ __forceinline__ float present_srgb(float c) {
-    float sel = ceilf(c - 0.0031308f);
-    float under = 12.92f * c;
-    float over = 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * 0.41666f) - 0.055f;
-    return sel > 0.0f ? over : under;  // mix(under, over, sel) with sel in {0, 1}
-}
 __global__ __launch_bounds__(256) void present_kernel(const void *__restrict__ bb, int fmt, uint32_t bw, uint32_t bh,
                                                       uint32_t w, uint32_t h, uint32_t *__restrict__ rgba8,
                                                       uint32_t *__restrict__ bgra8) {
@@ -57,16 +47,10 @@ __global__ __launch_bounds__(256) void present_kernel(const void *__restrict__ b
             px[k] = fmaf(fy, b - a, a);
         }
     }
-    float c[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float v = px[k];
-        if (k < 3) v = present_srgb(aces_film(v));
-        c[k] = floorf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);
-    }
-    uint32_t r = (uint32_t)c[0], g = (uint32_t)c[1], b = (uint32_t)c[2], al = (uint32_t)c[3];
-    rgba8[id] = r | (g << 8) | (b << 16) | (al << 24);
-    if (bgra8) bgra8[id] = b | (g << 8) | (r << 16) | (al << 24);
+    uint32_t rgba, bgra;
+    present_pack(px, rgba, bgra);  // (vk_common.hpp: shared with the fused epilogue)
+    rgba8[id] = rgba;
+    if (bgra8) bgra8[id] = bgra;
 }
 
 // Root side of a batched multi-GPU launch: gathered [nranks][slot][frame][ts][ts] (slot < n_slots) -> frames [B][H][W].

@@ -122,8 +122,14 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     int crc = check_render(ctx, mode, ctx->have_camera ? ctx->camera : nullptr, dt_scale, ts, rank, nranks);
     if (crc) return crc;
     const int geo_mode = mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode;
+    constexpr uint32_t kPresentFlags = VK_RENDER_PRESENT | VK_RENDER_PRESENT_BGRA | VK_RENDER_PRESENT_ONLY;
+    if ((flags & kPresentFlags) && compact_out) return fail(ctx, VK_ERR_INVALID, "VK_RENDER_PRESENT*: whole-pixel passes into the backbuffer only (vk_render)");
     if (rw == 0 || rh == 0) return VK_OK;  // empty tile
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (flags & kPresentFlags) {  // the present target at the backbuffer's own size, as vk_present(width, height) would make it
+        int prc = present_targets(ctx, ctx->width, ctx->height, (flags & VK_RENDER_PRESENT_BGRA) != 0);
+        if (prc) return prc;
+    }
     const bool count = (flags & VK_RENDER_COUNT) != 0;
     if (count && !ctx->steps) {
         HIP_TRY(ctx, hipMalloc(&ctx->steps, (size_t)ctx->width * ctx->height * sizeof(uint32_t)));
@@ -174,6 +180,11 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     L.pair_walk_min = ctx->pair_walk_min;
+    if (flags & kPresentFlags) {
+        L.present_rgba8 = ctx->rgba8;
+        L.present_bgra8 = (flags & VK_RENDER_PRESENT_BGRA) ? ctx->bgra8 : nullptr;
+        L.present_only = (flags & VK_RENDER_PRESENT_ONLY) ? 1u : 0u;
+    }
     if (count && ctx->want_trace) {
         // (a per-trip log of trip_log_cap u32 per wave = trip_log_cap / 8 records of the stamps' size)
         const uint64_t recs = ctx->trip_log_cap ? n_blocks * (ctx->trip_log_cap / 8u) : n_blocks;
