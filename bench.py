@@ -7,18 +7,18 @@ fraction of the HBM-read roofline (BASELINE.json / SURVEY.md 8d, config C2).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 (typed without torchrun, `--gpus N` with N > 1 starts its own ranks as a child torch.distributed.run and relays the line)
 
-A "step" is one frame: one pass of the raycast over every pixel.  Frames are submitted `batch` at a time: ONE launch
-spans the batch (vk_render_batch; the reference keeps frames in flight through its queue, src/lib.rs:178-194).
-At N = 1 the launch writes whole frames.  At N > 1 the SAME frames are partitioned: 64x64-pixel tiles dealt
-heaviest-first over the ranks, every rank marches its tiles of the batch in one launch, one RCCL gather (the library's
-own communicator, vk_gather_tiles) brings them to rank 0 over xGMI on a second stream while the next batch is
-marched, rank 0 un-tiles (scaling: strong -- the frames are fixed).
+A "step" is one LAUNCH: one pass of the raycast over a batch of `batch` frames, every frame its own camera (vk_render_batch; the
+reference keeps frames in flight through its queue, src/lib.rs:178-194).  K steps are timed, exactly.  At N = 1 the launch writes
+whole frames.  At N > 1 the SAME frames are partitioned: 64x64-pixel tiles dealt heaviest-first over the ranks, every rank marches its
+tiles of the batch in one launch, one RCCL gather (the library's own communicator, vk_gather_tiles) brings them to rank 0 over xGMI on
+a second stream while the next batch is marched, rank 0 un-tiles (scaling: strong -- the frames are fixed).
+`latency` holds the other shape of the same workload, the reference's own: ONE vk_render per frame, each frame a camera the caller did
+not know a frame earlier -- on one stream, and with 2 / 3 / 4 frames in flight (vk_ctx_frames_in_flight), with and without the present pass.
 
 value   = S_ref * M / t  [Mray-steps/s]: S_ref = loop iterations the reference shader executes for one frame (with its
           alpha >= 0.95 early-out), counted by the kernel itself in untimed counting launches (the mean over the
           launch's cameras) and equal to the oracle's count (tests).  Volume resident in HBM.  ONE contiguous timed
-          window of M >= max(100, 4 launches) frames, M a multiple of K (SURVEY 8d asks for >= 100 timed frames, and a
-          gather pipeline only fills over several launches): `timed_frames`, `launches_per_region`; the same rule at
+          window of exactly K steps (M = K * batch frames; `timed_frames`, `launches_per_region`), the same rule at
           every N.  The window is repeated 3 times and the median reported (`repeats`, `repeat_ms_per_step` in run
           order); an untimed pre-roll of the same path brings the GPU to its sustained clocks first (`preroll_frames`).
           The frames of a launch are consecutive frames of an orbit around the config's camera (yaw step 2 pi / 1024),
@@ -87,8 +87,8 @@ DT_SCALE = 0.5
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step is one launch of --batch frames (every frame its own camera)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps (launches) before the window")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE config to run (the metric is quoted on c2)")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch (default 128 for c2 -- 32 N at N > 1, at least 128, at most 256 --, 4 for c4 and c5)")
     ap.add_argument("--no-skip", action="store_true", help="disable exact empty-space skipping in the timed path")
@@ -236,7 +236,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         ms_c = time_launches(ctx, lambda: p.record(ctx), frames, warm=2)
         alg_c = c_samp * cfg["b_step"] + W * H * B_RAY
         core = {"launch_ms": ms_c, "s_ref": c_ref, "s_sampled": c_samp, "Mray_steps_per_s": c_ref / ms_c / 1e3,
-                "frac": alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "algorithmic_frac": alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS}
         phys = {}
         try:  # physical HBM side of the same kernel from the PMC passes (algorithmic bytes are served from LDS: their fraction says nothing about HBM)
             uj = json.load(open(os.path.join(ROOT, "profiles", PROF + "_utilisation.json"))).get(key, {})
@@ -247,9 +247,15 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
                                          "source": "profiles/%s_utilisation.json (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes; refetch = bytes fetched / dense volume bytes)" % PROF}}
         except Exception:
             pass
-        return {"dense_core": core, "workload": cfg["name"], **phys, "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
-                "algorithmic_bytes_per_launch": alg, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS, "volume_setup_s": setup,
-                "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, "frac": alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        staged = lay.value == 6
+        # A staged march serves its taps from LDS: the algorithmic bytes (8 taps per step) are not HBM traffic and their rate over the HBM peak is
+        # not bounded by 1 -- it is named `algorithmic_frac`, never `frac`, and the physical side (bytes the counters saw) comes first.
+        fkey = "algorithmic_frac" if staged else "frac"
+        return {"workload": cfg["name"], **phys, "launch_ms": ms, "s_ref": s_ref, "s_sampled": s_samp, "Mray_steps_per_s": s_ref / ms / 1e3,
+                "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": gb, fkey: gb / HBM_PEAK_GBS,
+                **({"algorithmic_frac_note": "8 B (u8) / 16 B (f16) per step over 8 TB/s: an accounting of the taps the LDS windows serve, not a bound; the HBM side is `physical_hbm`"} if staged else {}),
+                "volume_setup_s": setup, "dense_core": core,
+                "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, fkey: alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
                 "volume_device_bytes": nbytes.value, "kernel": "vk::raymarch_staged_kernel" if lay.value == 6 else "vk::raymarch_naive_kernel"}
     finally:
@@ -282,12 +288,12 @@ def c5_at_n(world, timeout_s=240):
         d = json.loads(lines[-1])
         res = {"workload": d["config"]["workload"], "n_gpus": d["n_gpus"], "frames_per_launch": d["frames_per_launch"], "timed_frames": d["timed_frames"],
                "s_ref_per_frame": d["config"]["s_ref_config_camera"], "volume_setup_s": d.get("volume_setup_s"),
-               "fixed_root": {"value": d["value"], "unit": d["unit"], "ms_per_frame": d["ms_per_step"], "frac": d["roofline"]["frac"], "root_skip": d["config"].get("root_skip")},
+               "fixed_root": {"value": d["value"], "unit": d["unit"], "ms_per_frame": d["ms_per_frame"], "frac": d["roofline"]["frac"], "root_skip": d["config"].get("root_skip")},
                "note": "`bench.py --gpus %d --config c5` as a child job after this one's ranks left their process group: C5 frames through the same partition + "
                        "gather + un-tile as the headline's (64 x 64-pixel tiles dealt heaviest-first, volume replicated: 26 GB of 288 per GPU)" % world}
         if "rotating_root" in d:
             rr = d["rotating_root"]
-            res["rotating_root"] = rr if "error" in rr else {"value": rr["value"], "unit": rr["unit"], "ms_per_frame": rr["ms_per_step"]}
+            res["rotating_root"] = rr if "error" in rr else {"value": rr["value"], "unit": rr["unit"], "ms_per_frame": rr["ms_per_frame"]}
         if "rehearsal" in d:
             res["rehearsal"] = d["rehearsal"]
         return res
@@ -352,7 +358,7 @@ def single_process_group(n_gpus, batch, s_ref, timeout_s=150):
             m = re.search(r"Avg frame time ([0-9.]+)ms", r.stdout)
             if r.returncode == 0 and m:
                 ms = float(m.group(1))
-                out[name] = {"ms_per_step": ms, "value": s_ref / ms / 1e3, "unit": "Mray-steps/s"}
+                out[name] = {"ms_per_frame": ms, "value": s_ref / ms / 1e3, "unit": "Mray-steps/s"}
             else:
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
         except subprocess.TimeoutExpired:
@@ -360,6 +366,88 @@ def single_process_group(n_gpus, batch, s_ref, timeout_s=150):
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": repr(e)}
     return out
+
+
+def frame_stream_ms(ctx, pipe, cams, n, in_flight, present=False):
+    """Wall time per frame of the one-vk_render-per-frame surface over n frames, every frame a camera of `cams` in turn (set just before the
+    frame is recorded, as Context::update does).  in_flight = 0: plain vk_render calls on the context's one stream; k >= 1: inside
+    vk_frame_begin / vk_frame_end on a ring of k surfaces.  Best of three windows after an untimed one."""
+    def window(m):
+        for j in range(m):
+            ctx.set_camera_blob(cams[j % len(cams)])
+            if in_flight:
+                ctx.frame_begin()
+            pipe.record(ctx)
+            if present:
+                ctx.render()
+            if in_flight:
+                ctx.frame_end()
+
+    window(min(n, 64))
+    ctx.sync()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        window(n)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        best = ms if best is None else min(best, ms)
+    return best
+
+
+def latency_section(V, torch, ctx, stream, cfg, flags, s_ref_still, s_sampled_still, cam_list, s_ref_orbit, s_sampled_orbit):
+    """The reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) on the headline's workload: the duration of
+    one single-frame launch on the config's camera, and the frame rate of a STREAM of such launches -- every frame a new camera of the
+    headline's orbit -- on one stream and with frames in flight (vk_ctx_frames_in_flight), bare and followed by the present pass
+    (two passes, and fused into the raycast's epilogue: VK_RENDER_PRESENT)."""
+    W, H = cfg["W"], cfg["H"]
+    n1 = 100 if cfg["n"] <= 256 else 24
+    alg_still = s_sampled_still * cfg["b_step"] + W * H * B_RAY
+    alg_orbit = s_sampled_orbit * cfg["b_step"] + W * H * B_RAY
+    p1 = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
+    evs1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
+    for _ in range(5):
+        p1.record(ctx)
+    for a, b in evs1:
+        a.record(stream)
+        p1.record(ctx)
+        b.record(stream)
+    torch.cuda.synchronize()
+    d = sorted(a.elapsed_time(b) for a, b in evs1)
+    ms1 = sum(d) / len(d)
+    gb = alg_still / (ms1 * 1e-3) / 1e9
+    lat = {"submission": "one vk_render per frame (the reference's model: one pass per RedrawRequested, src/lib.rs:178-181)",
+           "launch_ms": ms1, "launch_ms_p10": d[n1 // 10], "launch_ms_p50": d[n1 // 2], "launch_ms_p90": d[(9 * n1) // 10],
+           "value": s_ref_still / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
+           "note": "launch_ms: HIP events around each of %d back-to-back single-frame launches on the config's camera (kernel time; frames bitwise "
+                   "those of the batched launches)" % n1}
+    if cfg["n"] <= 256 and not (flags & (V.RENDER_NO_SKIP | V.RENDER_FAST_WALK)):
+        pf = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags | V.RENDER_FAST_WALK)
+        ms_f = time_launches(ctx, lambda: pf.record(ctx), 50, warm=10)
+        lat["fast_walk"] = {"launch_ms": ms_f, "value": s_ref_still / ms_f / 1e3, "note": "the same launch in tolerance mode (VK_RENDER_FAST_WALK)"}
+    # the stream of frames: wall time per frame, every frame its own orbit camera, set right before the frame is recorded
+    n = 256 if cfg["n"] <= 256 else 16
+    try:
+        ctx.set_stream(None)  # (a ring's surfaces run on streams of the context's own)
+        pf_ = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags | V.RENDER_PRESENT)
+        stream_of = {"frames": n, "unit": "ms per frame, wall time, every frame a new camera of the headline's orbit",
+                     "raycast": {}, "raycast_then_present": {}, "raycast_present_fused": {}}
+        for k in (0, 2, 3, 4):
+            if k:
+                ctx.frames_in_flight(k)
+            key = "one_stream" if k == 0 else "in_flight_%d" % k
+            stream_of["raycast"][key] = frame_stream_ms(ctx, p1, cam_list, n, k)
+            stream_of["raycast_then_present"][key] = frame_stream_ms(ctx, p1, cam_list, n, k, present=True)
+            stream_of["raycast_present_fused"][key] = frame_stream_ms(ctx, pf_, cam_list, n, k)
+        ctx.frames_in_flight(1)
+        best = min(stream_of["raycast"], key=lambda k_: stream_of["raycast"][k_])
+        msb = stream_of["raycast"][best]
+        stream_of["best"] = {"shape": best, "ms_per_frame": msb, "value": s_ref_orbit / msb / 1e3, "frac": alg_orbit / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        lat["in_flight"] = stream_of
+    finally:
+        ctx.frames_in_flight(1)
+        ctx.set_stream(stream.cuda_stream)
+    return lat
 
 
 def main():
@@ -386,14 +474,12 @@ def main():
         # often (docs/archive/tools/batch_size_at_n.py, a rank of 8: 14.7 / 11.6 / 9.9 / 8.8 us per frame at 16 / 32 / 64 / 128 frames per launch)
         batch = min(256, max(128, 32 * world))
     batch = max(1, batch)
-    # ONE contiguous timed window (>= 100 timed frames): M = the multiple of K that covers max(100, four launches)
-    # -- march, wire and un-tile of different launches only overlap when a window holds several of them -- the same rule at
-    # every N and for the world-of-one driver line.  The window's M frames go out in launches of (almost) equal size: a padded
-    # last launch would march frames nobody counts.
+    # A STEP is one launch: one pass of the raycast over a batch of `batch` frames, every frame its own camera.  The timed window is
+    # EXACTLY K steps = K launches = K * batch frames (>= 100 frames, SURVEY 8d, for any K at the default batch sizes of c2); the W
+    # warm-up steps are W launches of the same kind.
     K = max(1, args.steps)
-    timed_frames = K * -(-max(100, 4 * batch) // K)
-    n_launch = max(1, -(-timed_frames // batch))
-    batch = -(-timed_frames // n_launch)
+    n_launch = K
+    timed_frames = K * batch
     if batch > 1024:
         sys.exit("bench.py: --batch is at most 1024 frames per launch (VK_MAX_BATCH_FRAMES)")
 
@@ -540,7 +626,7 @@ def main():
             for _ in range(n_pre):
                 timed_region(batch, False)
             preroll_frames = (2 + n_pre) * batch
-        timed_region(args.warmup, False) if args.warmup else None
+        timed_region(args.warmup * batch, False) if args.warmup else None
         # The window of `timed_frames` frames, three times (a single window is at the mercy of one host hiccup -- a default
         # run on a busy box once reported 27.5 ms of wall time around 20.3 ms of launches); the median is reported.
         repeats = 3
@@ -550,7 +636,7 @@ def main():
             for _ in range(repeats):
                 del launch_ev[:]
                 runs.append((timed_region(timed_frames, True), [(a, b) for a, b in launch_ev]))
-            order_ms = [r[0] / timed_frames * 1e3 for r in runs]  # in the order they ran
+            order_ms = [r[0] / K * 1e3 for r in runs]  # in the order they ran
             runs.sort(key=lambda r: r[0])
             return runs[len(runs) // 2] + (order_ms,)
 
@@ -618,7 +704,8 @@ def main():
 
         if rank == 0:
             n_px = W * H
-            ms_per_step = elapsed / timed_frames * 1e3
+            ms_per_step = elapsed / K * 1e3          # a step: one launch of `batch` frames
+            ms_per_frame = elapsed / timed_frames * 1e3
             alg_frame = s_sampled * cfg["b_step"] + n_px * B_RAY
             out = {
                 "metric": cfg["metric"],
@@ -626,8 +713,9 @@ def main():
                 "unit": "Mray-steps/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "timed_frames": timed_frames, "launches_per_region": n_launch, "frames_per_launch": batch,
-                "ms_per_step": ms_per_step,
-                "timed_region_s": elapsed,  # wall time of the window `value` is computed from (the median of the three repetitions)
+                "ms_per_step": ms_per_step, "ms_per_frame": ms_per_frame,
+                "step": "one launch = %d frames, every frame its own camera" % batch,
+                "timed_region_s": float("%.6g" % elapsed),  # wall time of the window of K steps `value` is computed from (the median of the three repetitions)
                 "higher_is_better": True,
                 "scaling": "strong",
                 "vs_baseline": None,
@@ -644,20 +732,21 @@ def main():
                     "s_ref_per_frame": s_ref, "s_sampled_per_frame": s_sampled, "rays_per_frame": n_px,
                     "s_ref_config_camera": s_ref_still, "s_sampled_config_camera": s_sampled_still,
                     "cameras": "every frame its own camera: consecutive frames of an orbit around the config's camera, yaw step 2pi/1024 (step counts: mean over the launch's frames)",
-                    "window": "one contiguous window of %d frames = %d launches of %d (a multiple of --steps covering max(100, 4 launches))" % (timed_frames, n_launch, batch),
+                    "submission": "batched: %d frames per launch, one camera per frame (vk_render_batch); the one-vk_render-per-frame shape of the same workload: `latency`" % batch,
+                    "window": "one contiguous window of exactly %d steps = %d launches of %d frames = %d frames" % (K, n_launch, batch, timed_frames),
                     **({"transport": "library RCCL communicator (vk_gather_tiles)" if transport == "rccl" else "torch.distributed (RCCL)"} if use_dist else {}),
                 },
                 **({"rehearsal": "all ranks on ONE GPU over gloo: a test of the N > 1 flow, not a measurement"} if rehearsal else {}),
                 "repeats": repeats, "repeat_ms_per_step": run_order_ms, "preroll_frames": preroll_frames,
                 "device": info["device_name"], "volume_setup_s": t_volume,
                 # the same window with the config's one camera repeated in every frame of every launch
-                **({"still_camera": {"ms_per_step": still_elapsed / timed_frames * 1e3, "value": s_ref_still * timed_frames / still_elapsed / 1e6,
+                **({"still_camera": {"ms_per_step": still_elapsed / K * 1e3, "ms_per_frame": still_elapsed / timed_frames * 1e3, "value": s_ref_still * timed_frames / still_elapsed / 1e6,
                                      "s_ref_per_frame": s_ref_still, "s_sampled_per_frame": s_sampled_still,
                                      **({"launch_ms": still_launch_ms,
                                          "frac": (s_sampled_still * cfg["b_step"] + n_px * B_RAY) * batch / (still_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if still_launch_ms else {})}}
                    if still_elapsed is not None else {}),
                 # the headline's own window in tolerance mode (VK_RENDER_FAST_WALK), beside the bit-exact headline
-                **({"fast_walk": {"ms_per_step": fast_elapsed / timed_frames * 1e3, "value": s_ref * timed_frames / fast_elapsed / 1e6,
+                **({"fast_walk": {"ms_per_step": fast_elapsed / K * 1e3, "ms_per_frame": fast_elapsed / timed_frames * 1e3, "value": s_ref * timed_frames / fast_elapsed / 1e6,
                                   **({"launch_ms": fast_launch_ms, "frac": alg_frame * batch / (fast_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if fast_launch_ms else {}),
                                   "note": "same orbit window, skips advance the position in closed form (one fma per coordinate; the iteration count is exact: an integer "
                                           "budget): 930 of C2's 636 049 hit pixels differ from the bit-exact frame by more than 1e-4 (max 1.6e-3) at unchanged iteration counts "
@@ -676,11 +765,12 @@ def main():
                     "launch_ms": launch_ms, "frames_per_launch": n_launch_frames, "launches_timed": len(evs),
                     "algorithmic_bytes_per_launch": alg,
                     "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
-                    # the same launch priced at the reference's own step count (every iteration of the reference loop
-                    # reads 8 taps; skipped iterations are provably alpha == 0): a throughput equivalence, not a roofline
-                    "achieved_at_reference_steps": (s_ref * cfg["b_step"] + n_px * B_RAY) * n_launch_frames / (launch_ms * 1e-3) / 1e9,
+                    # the same launch priced at the reference's own step count (every iteration of the reference loop reads 8 taps; skipped
+                    # iterations are provably alpha == 0): a throughput equivalence in GB/s, deliberately NOT divided by a peak -- it is no roofline
+                    "GBps_if_every_reference_step_fetched": (s_ref * cfg["b_step"] + n_px * B_RAY) * n_launch_frames / (launch_ms * 1e-3) / 1e9,
                 }
-                out["roofline"]["frac_at_reference_steps"] = out["roofline"]["achieved_at_reference_steps"] / HBM_PEAK_GBS
+                if cfg["n"] > 256 or args.layout == "staged":
+                    out["roofline"]["frac_kind"] = "algorithmic: the staged march serves its taps from LDS, so this is an accounting of taps over the HBM peak, not a bound (physical side: extras / profiles)"
                 # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/prof.sh, tools/pmc_traffic.py)
                 # of THIS launch shape: the same orbit, the same number of frames per launch.  No figure for another shape is
                 # scaled to this one (round 2 did that); a shape that was not profiled reports null.
@@ -718,7 +808,7 @@ def main():
                 if rot_error is not None:
                     out["rotating_root"] = {"error": rot_error}
                 if rot_elapsed is not None:
-                    out["rotating_root"] = {"value": s_ref * timed_frames / rot_elapsed / 1e6, "unit": "Mray-steps/s", "ms_per_step": rot_elapsed / timed_frames * 1e3,
+                    out["rotating_root"] = {"value": s_ref * timed_frames / rot_elapsed / 1e6, "unit": "Mray-steps/s", "ms_per_step": rot_elapsed / K * 1e3, "ms_per_frame": rot_elapsed / timed_frames * 1e3,
                                             "note": "the same window with launch g assembled on rank g mod N (BatchTileRenderer(root='rotate')): complete frames end up "
                                                     "round-robin over the GPUs instead of on rank 0; `value` above is the gather to rank 0"}
                 out["scaling_baseline"] = "like-for-like N = 1 baseline of this driver: extras.dist_driver_world1 of the N = 1 line (same batch, same partition + gather + un-tile path)"
@@ -726,34 +816,12 @@ def main():
                 # what a peer puts on its link to the root per frame: its active slots, colour only (alpha is 1 in every pixel)
                 out["config"]["wire"] = wire_info
 
-        # One frame per launch -- the reference's own submission model (one pass per RedrawRequested, src/lib.rs:178-181) -- on the
-        # config's camera: duration of a single-frame launch and its spread, back to back on a busy GPU.
+        # One vk_render per frame -- the reference's own submission model -- on the same workload: `latency`
         if rank == 0 and world == 1 and not args.headline_only:
             try:
-                n1 = 100 if args.config == "c2" else 24
-                p1 = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags)
-                evs1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
-                for _ in range(5):
-                    p1.record(ctx)
-                for a, b in evs1:
-                    a.record(stream)
-                    p1.record(ctx)
-                    b.record(stream)
-                torch.cuda.synchronize()
-                d = sorted(a.elapsed_time(b) for a, b in evs1)
-                ms1 = sum(d) / len(d)
-                gb = (s_sampled_still * cfg["b_step"] + W * H * B_RAY) / (ms1 * 1e-3) / 1e9
-                out["single_frame"] = {"launch_ms": ms1, "launch_ms_p10": d[n1 // 10], "launch_ms_p50": d[n1 // 2], "launch_ms_p90": d[(9 * n1) // 10],
-                                       "value": s_ref_still / ms1 / 1e3, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS,
-                                       "note": "one vk_render per frame (the reference's submission model), the config's camera, %d launches back to back; "
-                                               "single-frame launches of the skip kernels request the next position's distance byte under the current sample "
-                                               "(profiles/r04_probe_ahead.txt), frames bitwise those of the batched launches" % n1}
-                if args.config == "c2" and not args.no_skip and not args.fast_walk:
-                    pf = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT_SCALE, flags=flags | V.RENDER_FAST_WALK)
-                    ms_f = time_launches(ctx, lambda: pf.record(ctx), 50, warm=10)
-                    out["single_frame"]["fast_walk"] = {"launch_ms": ms_f, "value": s_ref_still / ms_f / 1e3, "note": "the same launch in tolerance mode (VK_RENDER_FAST_WALK)"}
-            except Exception as e:
-                out["single_frame"] = {"error": str(e)}
+                out["latency"] = latency_section(V, torch, ctx, stream, cfg, flags, s_ref_still, s_sampled_still, cam_list, s_ref, s_sampled)
+            except Exception as e:  # a side measurement must not take the headline down
+                out["latency"] = {"error": repr(e)}
 
         # untimed side measurements (rank 0, N = 1)
         if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
@@ -873,6 +941,15 @@ def main():
                     extras["xor_compute_nearest_720p_batch8"] = {"launch_ms": msb, "frames_per_launch": 8, "Mray_steps_per_s": sr * 8 / msb / 1e3,
                                                                  "achieved_GBps": gbb, "frac": gbb / HBM_PEAK_GBS}
                     del xfr
+                    # the xor example's own loop: one `single` dispatch per frame, the camera turning; one stream, and frames in flight
+                    xcams = [V.Camera(3.0, -0.5, 1.0 + 6.28318 * j / 1024, (0.0, 0.0, 0.0), 1280 / 720).get_proj_view_matrix() for j in range(128)]
+                    fl = {}
+                    for k in (0, 2, 3, 4):
+                        if k:
+                            cx.frames_in_flight(k)
+                        fl["one_stream" if k == 0 else "in_flight_%d" % k] = frame_stream_ms(cx, pc, xcams, 256, k)
+                    cx.frames_in_flight(1)
+                    extras["xor_compute_nearest_720p"]["frame_stream_ms_per_frame"] = fl
                 finally:
                     cx.close()
             except Exception as e:  # a side measurement must not take the headline down
@@ -907,10 +984,11 @@ def main():
         # co-headlines inside `roofline` (the driver's record keeps that object whole): the reference's submission model, one frame per
         # launch, and the sampling loop's own fraction -- the same kernel family with every step fetching its taps -- measured in this run
         if rank == 0 and "roofline" in out:
-            sf = out.get("single_frame", {})
+            sf = out.get("latency", {})
             if "launch_ms" in sf:
                 out["roofline"]["single_frame"] = {"launch_ms": sf["launch_ms"], "Mray_steps_per_s": sf["value"], "frac": sf["frac"], "measured_in_this_run": True,
-                                                   **({"tolerance_walk_launch_ms": sf["fast_walk"]["launch_ms"]} if "fast_walk" in sf else {})}
+                                                   **({"tolerance_walk_launch_ms": sf["fast_walk"]["launch_ms"]} if "fast_walk" in sf else {}),
+                                                   **({"frames_in_flight_best": sf["in_flight"]["best"]} if "best" in sf.get("in_flight", {}) else {})}
             ex = out.get("extras", {})
             if "frac" in ex.get("standin_noskip", {}):
                 out["roofline"]["dense_kernel"] = {"frac_single_frame": ex["standin_noskip"]["frac"], "frac_8_frames_per_launch": ex.get("standin_noskip_batch8", {}).get("frac"),

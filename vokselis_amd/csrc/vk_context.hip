@@ -131,8 +131,10 @@ int vk_ctx_destroy(vk_ctx *ctx) {
     if (!ctx) return VK_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)frames_drain(ctx);
-    frame_slot_switch(ctx, 0);  // slot 0 runs on own_stream (destroyed below); its surface is in the fields freed below
-    for (uint32_t i = 0; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], i == 0);
+    frame_slot_switch(ctx, 0);  // (slot 0's surface is in the fields freed below)
+    for (uint32_t i = 0; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], false);
+    if (ctx->fif_k > 1) ctx->stream = ctx->own_stream;  // (the ring's streams are gone)
+    ctx->fif_k = 1;
     comm_release(ctx);
     free_volume(ctx);
     if (ctx->backbuffer) (void)hipFree(ctx->backbuffer);
@@ -235,28 +237,38 @@ int vk_ctx_frames_in_flight(vk_ctx *ctx, uint32_t k) {
     int drc = frames_drain(ctx);
     if (drc) return drc;
     frame_slot_switch(ctx, 0);
-    ctx->stream = ctx->fif_k > 1 ? ctx->own_stream : ctx->stream;  // (slot 0 of a ring runs on own_stream)
     for (uint32_t i = 0; i < VK_MAX_FRAMES_IN_FLIGHT; i++) { ctx->fif[i].id = 0; ctx->fif[i].ended = false; }
     ctx->fif_seq = 0;
     for (int i = 0; i < 16; i++) { ctx->ring_use_stream[i] = nullptr; ctx->ring_use_frame[i] = 0; }  // (drained: no reader is left)
     for (uint32_t i = k; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], false);  // a smaller ring
-    if (k == 1) {
-        ctx->fif[0].stream = nullptr;  // one slot: on whatever stream the context runs on
+    auto one_slot = [&]() {  // one slot: on the context's own stream (or the caller's, vk_ctx_set_stream)
+        if (ctx->fif[0].stream) { (void)hipStreamDestroy(ctx->fif[0].stream); ctx->fif[0].stream = nullptr; }
+        if (ctx->fif_k > 1) ctx->stream = ctx->own_stream;
         ctx->fif_k = 1;
-        return VK_OK;
-    }
-    ctx->fif[0].stream = ctx->own_stream;
+    };
+    if (k == 1) { one_slot(); return VK_OK; }
+    // The ring's streams.  The ROCm runtime multiplexes a process's streams onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES,
+    // 4 by default), and two slots that land on one queue run one after the other -- in a process that already holds a handful of streams
+    // (PyTorch's, other contexts') exactly that happened to default-priority slot streams (three in flight ran like two).  The slots
+    // therefore take streams of the highest priority level, a queue pool of their own: VK_MAX_FRAMES_IN_FLIGHT of them fit it, and frames --
+    // the latency-bound work of the process -- are not queued behind its other launches.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const uint32_t old_k = ctx->fif_k;
-    ctx->fif_k = k;  // (frame_slot_switch moves streams once the ring has more than one slot)
     int rc = VK_OK;
-    for (uint32_t i = 1; i < k && rc == VK_OK; i++) {
+    for (uint32_t i = 0; i < k && rc == VK_OK; i++) {
         vk_ctx::FrameSlot &s = ctx->fif[i];
         if (!s.stream) {
-            hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-            if (e != hipSuccess) { rc = fail(ctx, VK_ERR_HIP, std::string("vk_ctx_frames_in_flight: hipStreamCreate: ") + hipGetErrorString(e)); break; }
+            hipError_t e = hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_greatest);
+            if (e != hipSuccess) rc = fail(ctx, VK_ERR_HIP, std::string("vk_ctx_frames_in_flight: hipStreamCreateWithPriority: ") + hipGetErrorString(e));
         }
-        if (i >= old_k && ctx->width) {  // a new slot takes the backbuffer's current shape, cleared
-            frame_slot_switch(ctx, i);
+    }
+    if (rc == VK_OK) {
+        ctx->fif_k = k;  // (frame_slot_switch moves streams once the ring has more than one slot)
+        ctx->stream = ctx->fif[0].stream;
+        for (uint32_t i = std::max(old_k, 1u); i < k && rc == VK_OK; i++) {
+            if (!ctx->width) break;  // (no backbuffer yet: vk_backbuffer_resize sizes every slot)
+            frame_slot_switch(ctx, i);  // a new slot takes the backbuffer's current shape, cleared
             rc = surface_alloc_current(ctx);
             frame_slot_switch(ctx, 0);
         }
@@ -264,8 +276,8 @@ int vk_ctx_frames_in_flight(vk_ctx *ctx, uint32_t k) {
     if (rc != VK_OK) {  // back to one slot: never a ring with a slot that has no surface
         (void)frames_drain(ctx);
         for (uint32_t i = 1; i < VK_MAX_FRAMES_IN_FLIGHT; i++) frame_slot_release(ctx->fif[i], false);
-        ctx->fif[0].stream = nullptr;
-        ctx->fif_k = 1;
+        ctx->fif_k = std::max(ctx->fif_k, 2u);  // (so that one_slot moves the context back to its own stream)
+        one_slot();
         return rc;
     }
     return frames_drain(ctx);  // (the clears)

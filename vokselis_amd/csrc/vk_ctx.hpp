@@ -131,7 +131,7 @@ struct vk_ctx {
         void *backbuffer = nullptr;
         uint32_t *steps = nullptr, *rgba8 = nullptr, *bgra8 = nullptr;
         uint32_t present_w = 0, present_h = 0;
-        hipStream_t stream = nullptr;  // fif_k > 1: slot 0 = own_stream, the others created with the ring
+        hipStream_t stream = nullptr;  // fif_k > 1: the slot's stream, created with the ring at the highest stream priority (vk_ctx_frames_in_flight)
         hipEvent_t done = nullptr;     // recorded by vk_frame_end
         uint64_t id = 0;               // the frame the slot holds (0: none)
         bool ended = false;            // ... and whether vk_frame_end has recorded `done` for it
