@@ -466,6 +466,14 @@ static inline float smoothstepf(float e0, float e1, float x) {
     return (s * s) * fmaf(-2.0f, s, 3.0f);
 }
 
+/* smoothstep AS WRITTEN in the WGSL specification -- t = clamp((x - e0) / (e1 - e0), 0, 1); t * t * (3 - 2 t) -- a true divide, every
+ * operation rounded on its own: the literal reading of raycast_compute.wgsl:79,82 and shaders/xor.wgsl:59 (VO_FLAG_LITERAL_WGSL). */
+static inline float smoothstep_literal(float e0, float e1, float x) {
+    float s = (x - e0) / (e1 - e0);
+    s = vmin(vmax(s, 0.0f), 1.0f);
+    return s * s * (3.0f - 2.0f * s);
+}
+
 static void load_rgba16f(const uint16_t *vol, uint32_t nx, uint32_t ny, uint32_t nz, int ix, int iy, int iz,
                          float o[4]) {
     /* naga bounds policy is Unchecked (src/utils/shader_compiler.rs:89-94): out-of-range texel
@@ -485,7 +493,7 @@ static inline int trunc_i32(float f) {
     return (int)f;
 }
 
-static void xor_noise_volume(const float c[3], float time, float out[4]);
+static void xor_noise_volume_ex(const float c[3], float time, float out[4], int literal);
 
 /* C3: the "procedural, no volume texture" configuration.  The reference has no such example
  * (F4); this build defines it as the compute twin's ray and march (render/get_col2, raycast_compute.wgsl:62-131)
@@ -510,11 +518,14 @@ static void pixel_procedural(const vo_render_args *a, uint32_t gx, uint32_t gy, 
         const float p[3] = {eye[0] + t * dir[0], eye[1] + t * dir[1], eye[2] + t * dir[2]};
         const float c[3] = {p[0] * 0.5f, p[1] * 0.5f, p[2] * 0.5f};
         float vol[4];
-        xor_noise_volume(c, a->proc_time, vol);
+        const int literal = (a->flags & VO_FLAG_LITERAL_WGSL) != 0;
+        xor_noise_volume_ex(c, a->proc_time, vol, literal);
         n++;
         const float vc = vol[0] / 2.0f;
-        float va = (vol[3] * vol[3]) * vol[3];
-        va = smoothstepf(0.0f, 0.7f, va);
+        /* raycast_compute.wgsl:78-79: pow(a, 3.0) then smoothstep(0.0, 0.7, .) -- specified as a * a * a and the reciprocal form;
+         * the literal reading calls powf and divides */
+        float va = literal ? powf(vol[3], 3.0f) : (vol[3] * vol[3]) * vol[3];
+        va = literal ? smoothstep_literal(0.0f, 0.7f, va) : smoothstepf(0.0f, 0.7f, va);
         const float w = (1.0f - A) * va;
         for (int k = 0; k < 3; k++) C[k] = C[k] + w * vc;
         A = A + w;
@@ -564,10 +575,14 @@ static void pixel_compute(const vo_render_args *a, uint32_t gx, uint32_t gy, flo
         /* shade = max(0, dot(light, normal)), light = (0,-1,0) */
         float sh = vmax(0.0f, (0.0f * nm[0] + -1.0f * nm[1]) + 0.0f * nm[2]);
         float shade[3] = {sh, sh, sh};
-        float va = (vc[3] * vc[3]) * vc[3]; /* pow(a, 3.0) as a*a*a */
-        va = smoothstepf(0.0f, 0.7f, va);
+        /* :78-79,82.  Specified reading: pow(a, 3.0) as a*a*a, smoothstep through the reciprocal of its span and one fma.
+         * VO_FLAG_LITERAL_WGSL: powf, smoothstep with its divide, every operation rounded on its own (mix, dot and the
+         * compositing below are already the text's own operations in the text's order). */
+        const int literal = (a->flags & VO_FLAG_LITERAL_WGSL) != 0;
+        float va = literal ? powf(vc[3], 3.0f) : (vc[3] * vc[3]) * vc[3];
+        va = literal ? smoothstep_literal(0.0f, 0.7f, va) : smoothstepf(0.0f, 0.7f, va);
         float dl = vmax(dot3(nm, l1), 0.0f);
-        float ss = smoothstepf(0.3f, 1.5f, dot3(p, l2));
+        float ss = literal ? smoothstep_literal(0.3f, 1.5f, dot3(p, l2)) : smoothstepf(0.3f, 1.5f, dot3(p, l2));
         float dirl[3] = {3.0f * 1.0f * dl * ss, 3.0f * 0.1f * dl * ss, 3.0f * 0.13f * dl * ss};
         float col[3] = {vc[0] + dirl[0], vc[1] + dirl[1], vc[2] + dirl[2]};
         float bl = 0.9f * vmin(vmax(0.5f - 0.5f * nm[1], 0.0f), 1.0f);
@@ -687,15 +702,18 @@ static float xor_fbm(const float p0[3]) { /* xor.wgsl:35-44 */
     return f;
 }
 
-static void xor_noise_volume(const float c[3], float time, float out[4]) { /* xor.wgsl:55-61 */
+/* literal != 0: the falloff's smoothstep(0.5, 0.25, length(coord)) with its divide (xor.wgsl:59 as written); the hash's sine stays
+ * the specified one either way (a device's own sine is not a reading of the text but another function: SURVEY 8d C3) */
+static void xor_noise_volume_ex(const float c[3], float time, float out[4], int literal) { /* xor.wgsl:55-61 */
     float off[3] = {1.0f, sin_spec(time * 1.0f) * 0.1f, 21.0f};
     float pos[3] = {(c[0] + off[0]) * 32.0f, (c[1] + off[1]) * 32.0f, (c[2] + off[2]) * 32.0f};
     float val = xor_fbm(pos);
     float len = sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
-    float alpha = val * smoothstepf(0.5f, 0.25f, len);
+    float alpha = val * (literal ? smoothstep_literal(0.5f, 0.25f, len) : smoothstepf(0.5f, 0.25f, len));
     out[0] = out[1] = out[2] = val;
     out[3] = alpha;
 }
+static void xor_noise_volume(const float c[3], float time, float out[4]) { xor_noise_volume_ex(c, time, out, 0); }
 
 void vo_volume_xor(uint32_t nx, uint32_t ny, uint32_t nz, float time, uint16_t *density, uint16_t *normals) {
     const float dims[3] = {(float)nx, (float)ny, (float)nz};

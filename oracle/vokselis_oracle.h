@@ -60,7 +60,10 @@ enum {
     /* NAIVE mode: evaluate raycast_naive.wgsl:96-119 AS WRITTEN instead of as specified -- texel coordinate p*n - 0.5 with two
      * roundings, every R8Unorm tap divided by 255, lerps a + f*(b - a) without fused operations, smoothstep's (v - 0.1) / (1.2 -
      * 0.1) as a true divide, the background term kept, libm cosf / powf.  The yardstick for the distance between "what the
-     * shader says" and "what the three implementations agree on" (DESIGN.md 2.1); never the checker of the HIP path. */
+     * shader says" and "what the three implementations agree on" (DESIGN.md 2.1); never the checker of the HIP path.
+     * COMPUTE_NEAREST / PROCEDURAL (round 6): raycast_compute.wgsl:62-97 as written -- pow(a, 3.0) through powf, both smoothsteps (and
+     * xor.wgsl:59's, in PROCEDURAL) with their divide and no fused operation; mix, dot and the compositing are the text's own
+     * operations in the text's order in either reading. */
     VO_FLAG_LITERAL_WGSL = 8,
     VO_FLAG_TRANSFER_R1 = 16 /* NAIVE mode: the round-1 text of the transfer function (vo_transfer_alpha_r1) in an otherwise specified march */
 };

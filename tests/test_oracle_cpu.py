@@ -289,6 +289,24 @@ def test_literal_wgsl_yardstick(O):
     assert max(abs(L.vo_transfer_alpha(float(x), 1) - L.vo_transfer_alpha_literal(float(np.float32(x) / np.float32(255.0)))) for x in xs) <= 2.5e-7
 
 
+def test_literal_wgsl_yardstick_compute_and_procedural(O):
+    """VO_FLAG_LITERAL_WGSL for the other two kernel families: raycast_compute.wgsl:62-97 as written -- pow(a, 3.0) through powf, both
+    smoothsteps with their divide and no fused operation -- and, for the procedural mode, xor.wgsl:59's falloff the same way.  Against the
+    specified reading (a*a*a, reciprocal-and-fma smoothstep) on the xor example at 640x360 (128^3 pair) and C3 at 320x180: NO pixel changes
+    its trip count, max |dRGBA| stays at rounding level (measured 6e-8 / 1.2e-7; bar 1e-5)."""
+    n, W, H = 128, 640, 360
+    den, nrm = O.volume_xor(n, 0.0)
+    cam = O.camera_blob(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H)
+    a, sa, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
+    b, sb, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm, flags=O.FLAG_LITERAL_WGSL)
+    assert (sa == sb).all() and (sa > 0).mean() > 0.15
+    assert 0 < np.abs(a - b).max() <= 1e-5  # (the two readings are different arithmetic: not bitwise equal)
+    pa, psa = O.render_procedural(cam, 320, 180)
+    pb, psb = O.render_procedural(cam, 320, 180, flags=O.FLAG_LITERAL_WGSL)
+    assert (psa == psb).all() and (psa > 0).mean() > 0.15
+    assert 0 < np.abs(pa - pb).max() <= 1e-5
+
+
 def test_volume_png_pin(O):
     """The one reference-held pin (oracle/volume_png.py): xor.wgsl generator at t = 0 -> raycast_compute.wgsl at 1280x720 ->
     present.wgsl to the capture's 958x1050, at the camera fitted to the reference's `volume.png`.  The capture itself travels

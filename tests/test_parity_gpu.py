@@ -1415,6 +1415,11 @@ def test_baseline_configs_full_size(V, O, name, n, f16, W, H, seed, tile):
     assert (steps["auto"][ys, xs] == rsteps[ys, xs]).all()
     assert rsteps[ys, xs].min() > 100  # the tile lies inside the cube's silhouette
     assert np.abs(imgs["auto"][ys, xs] - ref[ys, xs]).max() <= TOL
+    # ... and the shader's text AS WRITTEN (VO_FLAG_LITERAL_WGSL: two-rounding coordinate, unfused lerps, smoothstep's divide, libm), on
+    # the same tile -- the staged kernels (f16 taps on C4, u8 taps on C5) held to the literal reading: no trip count moves, <= 1e-5
+    lit, lsteps, _ = O.render(cam, host, W, H, dt_scale=0.5, tile=tile, flags=O.FLAG_LITERAL_WGSL)
+    assert (steps["auto"][ys, xs] == lsteps[ys, xs]).all(), (name, "literal trips")
+    assert np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max() <= 1e-5, (name, np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max())
 
 
 @pytest.mark.parametrize("name,n,f16,W,H,seed,tile", [
@@ -1454,6 +1459,11 @@ def test_baseline_configs_dense_core_full_size(V, O, name, n, f16, W, H, seed, t
     assert (steps["auto"][ys, xs] == rsteps[ys, xs]).all()
     assert rsteps[ys, xs].min() > 100 and 2 * rsteps[ys, xs].min() < rsteps[ys, xs].max()  # the tile straddles the silhouette
     assert np.abs(imgs["auto"][ys, xs] - ref[ys, xs]).max() <= TOL
+    # the literal reading of the shader on the same tile, where rays END by the alpha >= 0.95 early-out (the trip count is the
+    # sensitive quantity here): no trip count moves, <= 1e-5 per channel
+    lit, lsteps, _ = O.render(cam, host, W, H, dt_scale=0.5, tile=tile, flags=O.FLAG_LITERAL_WGSL)
+    assert (steps["auto"][ys, xs] == lsteps[ys, xs]).all(), (name, "literal trips", int((steps["auto"][ys, xs] != lsteps[ys, xs]).sum()))
+    assert np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max() <= 1e-5, (name, np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max())
 
 
 def test_raw_loader_round_trip(V, O, tmp_path):
@@ -1713,6 +1723,11 @@ def test_xor_example_full_size(V, O):
         assert np.abs(img - ref).max() <= TOL, (name, np.abs(img - ref).max())
         frames[name], sampled[name] = img, ss
     assert (frames["records"].view(np.uint32) == frames["literal"].view(np.uint32)).all()
+    # the record kernel against raycast_compute.wgsl:62-97 AS WRITTEN (VO_FLAG_LITERAL_WGSL: pow(a, 3.0) through powf, both smoothsteps
+    # with their divide, nothing fused): every pixel of the example's own frame -- no trip count moves, <= 1e-5 per channel
+    lit, lsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm, flags=O.FLAG_LITERAL_WGSL)
+    assert (lsteps == rsteps).all(), int((lsteps != rsteps).sum())
+    assert np.abs(frames["records"] - lit).max() <= 1e-5, np.abs(frames["records"] - lit).max()
     # exact empty-space skipping of the record kernel (round 4): not a bit changes, and the steps that fetch and shade are those whose
     # record can contribute plus a rim of one or two voxels -- the blob fills half of the cube, a ray sees far less of it
     assert (frames["records"].view(np.uint32) == frames["records_noskip"].view(np.uint32)).all()
@@ -1765,6 +1780,10 @@ def test_procedural_full_size_tiles(V, O):
         sl = (slice(ty, ty + th), slice(tx, tx + tw))
         assert (steps[sl] == rsteps[sl]).all(), (tx, ty)
         assert np.abs(img[sl] - ref[sl]).max() <= TOL, (tx, ty, np.abs(img[sl] - ref[sl]).max())
+        # the literal reading (powf, the march's and xor.wgsl:59's smoothsteps with their divide): no trip count moves, <= 1e-5
+        lit, lsteps = O.render_procedural(cam, W, H, tile=(tx, ty, tw, th), flags=O.FLAG_LITERAL_WGSL)
+        assert (steps[sl] == lsteps[sl]).all(), (tx, ty, "literal trips")
+        assert np.abs(img[sl] - lit[sl]).max() <= 1e-5, (tx, ty, np.abs(img[sl] - lit[sl]).max())
     assert rsteps[H // 2 - 32:H // 2 + 32].max() > 150
 
 
