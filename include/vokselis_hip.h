@@ -296,6 +296,11 @@ int vk_comm_available(void);
 int vk_comm_unique_id(void *id128);
 int vk_comm_init_rank(vk_ctx *ctx, const void *id128, int rank, int nranks);
 int vk_comm_destroy(vk_ctx *ctx);
+/* ABI 5.  Tear the communicator down WITHOUT waiting for what is in flight (ncclCommAbort): for a rank that has found a peer gone -- a
+ * gather that does not complete within the caller's time limit (vk_comm_destroy would wait on the stream the dead transfer sits on).
+ * Transfers in flight are cancelled, the buffers they were writing are undefined; the context stays usable and may join a new
+ * communicator.  No-op without a communicator. */
+int vk_comm_abort(vk_ctx *ctx);
 int vk_comm_info(vk_ctx *ctx, int *rank, int *nranks);
 /* Every rank contributes n_pixels pixels (of the partition's wire format: vk_partition_wire) from `send`; the root receives [nranks][n_pixels] in
  * `recv` (ignored elsewhere).  One grouped send/recv, asynchronous, on `hip_stream` (NULL: the context's stream; a

@@ -1,4 +1,4 @@
-// fake_rccl.cpp -- TEST INFRASTRUCTURE: the nine RCCL entry points libvokselis_hip.so binds (vk_comm.hip: RcclApi),
+// fake_rccl.cpp -- TEST INFRASTRUCTURE: the ten RCCL entry points libvokselis_hip.so binds (vk_comm.hip: RcclApi),
 // implemented inside ONE process with stream-ordered hipMemcpyAsync, so that the N > 1 branches of vk_gather_tiles and
 // vk_group_render execute on a box with a single GPU.  Loaded only when the environment
 // names it (VK_RCCL_LIB=tests/_build/libfake_rccl.so); the product never links it.
@@ -106,6 +106,21 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     if (!comm) return ncclInvalidArgument;
+    delete comm;
+    return ncclSuccess;
+}
+
+// ncclCommAbort: the communicator goes at once; sends / receives it had posted and that never met their partner are dropped
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+    if (!comm) return ncclInvalidArgument;
+    World &w = *comm->world;
+    for (auto *qs : {&w.sends, &w.recvs})
+        for (auto &q : *qs) {
+            const bool mine = (qs == &w.sends) ? q.first.first == comm->rank : q.first.second == comm->rank;
+            if (!mine) continue;
+            for (auto &p : q.second) if (p.posted) (void)hipEventDestroy(p.posted);
+            q.second.clear();
+        }
     delete comm;
     return ncclSuccess;
 }

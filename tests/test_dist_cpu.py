@@ -131,7 +131,7 @@ def test_bench_window_rule():
 
 def test_fake_rccl_builds_and_exports_the_bound_symbols():
     """The single-process stand-in for RCCL the gpu suite binds through VK_RCCL_LIB (tests/fake_rccl.cpp) builds here and
-    exports the nine entry points vk_comm.hip resolves (no call without a GPU)."""
+    exports the ten entry points vk_comm.hip resolves (no call without a GPU)."""
     import ctypes as C
 
     import __graft_entry__ as g
@@ -139,9 +139,9 @@ def test_fake_rccl_builds_and_exports_the_bound_symbols():
     if not (os.path.isdir("/opt/rocm/include/hip") and os.path.exists("/opt/rocm/lib/libamdhip64.so")):
         pytest.skip("no ROCm headers / runtime on this box: the stand-in links libamdhip64")
     lib = C.CDLL(g.build_fake_rccl())
-    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommAbort", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
                  "ncclGetErrorString", "fake_rccl_stats", "fake_rccl_unmatched"):
         assert getattr(lib, name) is not None
     src = open(os.path.join(ROOT, "vokselis_amd", "csrc", "vk_comm.hip")).read()
-    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommAbort", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString"):
         assert 'sym("%s")' % name in src, name

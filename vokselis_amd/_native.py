@@ -69,6 +69,7 @@ SYMBOLS = {
     "vk_comm_unique_id": (C.c_int, [_vp]),
     "vk_comm_init_rank": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "vk_comm_destroy": (C.c_int, [_vp]),
+    "vk_comm_abort": (C.c_int, [_vp]),
     "vk_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vk_gather_tiles": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
     "vk_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),

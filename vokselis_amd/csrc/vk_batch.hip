@@ -40,7 +40,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t ts = tile_size, tx = (ctx->width + ts - 1) / ts, ty = (ctx->height + ts - 1) / ts;
     const size_t n_tiles = (size_t)tx * ty;
-    const size_t bytes = (size_t)n_frames * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t));
+    const size_t bytes = batch_table_bytes(n_frames, n_tiles, sizeof(FrameDesc));  // (vk_hostmath.hpp: FrameDesc[B] | order[B][n_tiles] | pos[B][n_tiles])
     vk_ctx::BatchSlot &B = ctx->batch[ctx->batch_seq % 4u];
     if (B.ev) HIP_TRY(ctx, hipEventSynchronize(B.ev));  // the launches of four batches ago have long finished
     else HIP_TRY(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
@@ -59,7 +59,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         B.d = B.h = nullptr;
         // (the 256-frame floor is for drivers whose batches grow; it is capped at 4 MiB so that a one-frame batch at a small tile size --
         // ts = 8 at 1080p is 32 400 tiles -- does not pin 66 MB per slot)
-        const size_t floor256 = std::min<size_t>((size_t)256 * (sizeof(FrameDesc) + 2 * n_tiles * sizeof(uint32_t)), (size_t)4 << 20);
+        const size_t floor256 = std::min<size_t>(batch_table_bytes(256u, n_tiles, sizeof(FrameDesc)), (size_t)4 << 20);
         const size_t want = std::max({bytes, 2 * B.cap, floor256});
         B.cap = 0;
         HIP_TRY(ctx, hipMalloc((void **)&B.d, want));
@@ -67,7 +67,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
         B.cap = want;
     }
     FrameDesc *fd = reinterpret_cast<FrameDesc *>(B.h);
-    uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + (size_t)n_frames * sizeof(FrameDesc));
+    uint32_t *h_order = reinterpret_cast<uint32_t *>(B.h + batch_order_offset(n_frames, sizeof(FrameDesc)));
     uint32_t *h_pos = h_order + (size_t)n_frames * n_tiles;
     uint32_t max_active = 0, min_active = 0xffffffffu;
     // The tile order depends on the camera (and the frame / volume shape).  It is written straight into the pinned
@@ -174,7 +174,7 @@ int vk_render_batch(vk_ctx *ctx, int mode, uint32_t n_frames, const void *camera
     L.ox = 0; L.oy = 0; L.rw = ctx->width; L.rh = ctx->height;
     L.ts = ts; L.tiles_x = tx; L.tiles_y = ty;
     L.rank = rank; L.nranks = nranks; L.root_skip = root_skip;
-    L.tile_order = reinterpret_cast<const uint32_t *>(B.d + (size_t)n_frames * sizeof(FrameDesc));
+    L.tile_order = reinterpret_cast<const uint32_t *>(B.d + batch_order_offset(n_frames, sizeof(FrameDesc)));
     L.n_tiles_launch = 0;
     const uint64_t per_tile = (uint64_t)(ts / 8) * (ts / 8);
     const uint64_t n_blocks = slots * n_frames * per_tile;

@@ -24,6 +24,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,12 +53,13 @@ static bool rccl_load() {
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
     g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(sym("ncclCommAbort"));
     g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
     g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
     g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
     g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd ||
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.CommAbort || !g_rccl.GroupStart || !g_rccl.GroupEnd ||
         !g_rccl.Send || !g_rccl.Recv || !g_rccl.GetErrorString) { dlclose(h); return false; }
     g_rccl.lib = h;
     return true;
@@ -111,6 +113,20 @@ int vk_comm_destroy(vk_ctx *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     comm_release(ctx);
+    return VK_OK;
+}
+
+// A rank that has found a peer gone (a gather that does not complete within the caller's time limit) cannot use vk_comm_destroy: that
+// waits for the stream the dead transfer sits on.  ncclCommAbort cancels what is in flight and frees the communicator.
+int vk_comm_abort(vk_ctx *ctx) {
+    if (!ctx) return VK_ERR_INVALID;
+    if (ctx->in_group) return fail(ctx, VK_ERR_INVALID, "vk_comm_abort: this context belongs to a vk_group");
+    if (!ctx->comm) return VK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclComm_t c = ctx->comm;
+    const bool owned = ctx->comm_owned;
+    ctx->comm = nullptr; ctx->comm_size = 0; ctx->comm_rank = 0; ctx->comm_owned = false;
+    if (owned && g_rccl.lib) NCCL_TRY(ctx, g_rccl.CommAbort(c));
     return VK_OK;
 }
 

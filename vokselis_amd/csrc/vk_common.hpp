@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vk_hostmath.hpp"  // deal_*, block / pixel / record index maps (shared with the host and with tests/hostmath_fuzz.cpp)
+
 namespace vk {
 
 // ---- layouts ---------------------------------------------------------------------------------
@@ -159,32 +161,6 @@ __device__ __forceinline__ void set_wave_priority(bool hit, uint32_t left, float
     else __builtin_amdgcn_s_setprio(0);
 }
 
-// ---- dealing positions of the heaviest-first order to ranks ------------------------------------
-// Round j gives one position to every rank, in rank order.  With root_skip = k >= 2 the root (rank 0) sits out every
-// k-th round (rounds k-1, 2k-1, ...): it also un-tiles every frame, and a lighter share of the march keeps it from
-// being the rank everybody waits for.  k < 2: plain round robin, position q -> rank q % N, slot q / N.
-__host__ __device__ __forceinline__ uint32_t deal_pos(uint32_t rank, uint32_t slot, uint32_t N, uint32_t k) {
-    if (k < 2u) return rank + slot * N;
-    const uint32_t round = rank ? slot : slot + slot / (k - 1u);  // the root's slot j is its j-th full round
-    const uint32_t start = round * N - round / k;                 // one position less for every light round before
-    return start + rank - ((round % k) == k - 1u ? 1u : 0u);      // (the root never sees a light round)
-}
-__host__ __device__ __forceinline__ void deal_owner(uint32_t pos, uint32_t N, uint32_t k, uint32_t &rank, uint32_t &slot) {
-    if (k < 2u) { rank = pos % N; slot = pos / N; return; }
-    const uint32_t G = k * N - 1u, g = pos / G, o = pos - g * G;  // a group: k - 1 full rounds and a light one
-    uint32_t rj;
-    if (o < (k - 1u) * N) { rj = o / N; rank = o - rj * N; }
-    else { rj = k - 1u; rank = o - (k - 1u) * N + 1u; }
-    slot = rank ? g * k + rj : g * (k - 1u) + rj;
-}
-// rounds needed to deal `tiles` positions = slots of a non-root rank
-__host__ __device__ __forceinline__ uint32_t deal_rounds(uint32_t tiles, uint32_t N, uint32_t k) {
-    if (k < 2u) return (tiles + N - 1u) / N;
-    uint32_t r = tiles / N;
-    while (r * N - r / k < tiles) r++;
-    return r;
-}
-
 struct PixelMap {
     int32_t x, y;      // image coordinates
     bool valid;        // inside region and image
@@ -209,19 +185,11 @@ __device__ __forceinline__ FrameView frame_view(const LaunchDesc &L, uint32_t lb
     FrameView f;
     if (L.frames) {
         const uint32_t sps = L.ts >> 3, per_tile = sps * sps;
-        const uint32_t g = lb / per_tile, sub = lb - g * per_tile;  // g: (slot, frame) pairs, frame fastest
-        const uint32_t slot = g / L.n_frames;
-        uint32_t fr = g - slot * L.n_frames;
-        if (L.flags & LF_FRAME_RUNS) {
-            // Consecutive g go to consecutive XCDs (logical_block), so with the frame index running fastest XCD x would march frames x, x + 8,
-            // x + 16 ... of a tile position.  Under a moving camera neighbouring frames share almost all of their cells (a few pixels of shift),
-            // frames eight apart far fewer: give every XCD a run of CONSECUTIVE frames instead -- residue x of the position takes frames
-            // [start_x, start_x + count_x) -- so that a position's frames meet in one L2, one after the other.  A relabelling only.
-            const uint32_t x = fr & 7u, j = fr >> 3, q = L.n_frames >> 3, rem = L.n_frames & 7u;
-            fr = x * q + min(x, rem) + j;
-        }
-        f.frame = fr;
-        f.lb = slot * per_tile + sub;
+        // (slot, frame) pairs, frame fastest; with LF_FRAME_RUNS every XCD marches a run of CONSECUTIVE frames of a tile position: under a moving
+        // camera neighbouring frames share almost all of their cells, frames eight apart far fewer (vk_hostmath.hpp: batch_block_split)
+        const BlockSplit bs = batch_block_split(lb, per_tile, L.n_frames, (L.flags & LF_FRAME_RUNS) != 0u);
+        f.frame = bs.frame;
+        f.lb = bs.slot * per_tile + bs.sub;
         const FrameDesc &d = L.frames[f.frame];
 #pragma unroll
         for (int i = 0; i < 4; i++) f.eye[i] = d.eye[i];
@@ -255,20 +223,17 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameVi
     uint32_t pos = deal_pos(L.rank, slot, L.nranks, L.root_skip);  // position in the heaviest-first order
     const uint32_t n_tiles = L.tiles_x * L.tiles_y;
     uint32_t tile = pos < fv.n_tiles_launch ? fv.order[pos] : n_tiles;
-    uint32_t tty = tile / L.tiles_x, ttx = tile - tty * L.tiles_x;
-    uint32_t sy = sub / sps, sx = sub - sy * sps;
-    uint32_t lx = sx * 8 + (lane & 7u), ly = sy * 8 + (lane >> 3);  // inside the tile
-    uint32_t rx = ttx * L.ts + lx, ry = tty * L.ts + ly;             // inside the region
+    const TilePixel tp = tile_pixel(L.ts, L.tiles_x, tile, sub, lane);  // (vk_hostmath.hpp)
+    const uint32_t lx = tp.lx, ly = tp.ly, rx = tp.rx, ry = tp.ry;
     m.x = L.ox + (int32_t)rx;
     m.y = L.oy + (int32_t)ry;
     m.valid = (tile < n_tiles) && rx < L.rw && ry < L.rh && m.x >= 0 && m.y >= 0 &&
               m.x < (int32_t)L.W && m.y < (int32_t)L.H;
     const uint32_t nf = L.frames ? L.n_frames : 1u;
     m.pos = pos;
-    m.rec = slot * nf + fv.frame;
+    m.rec = compact_record(slot, nf, fv.frame);
     m.rec_px = ly * L.ts + lx;
-    m.out_index = L.compact ? (size_t)m.rec * (L.ts * L.ts) + m.rec_px
-                            : ((size_t)fv.frame * L.H + (size_t)m.y) * L.W + (size_t)m.x;
+    m.out_index = L.compact ? compact_pixel_index(m.rec, L.ts, lx, ly) : frame_pixel_index(fv.frame, L.W, L.H, (uint32_t)m.x, (uint32_t)m.y);
     return m;
 }
 

@@ -178,7 +178,6 @@ void free_volume(vk_ctx *ctx);   // vk_volume.hip
 void comm_release(vk_ctx *ctx);  // vk_comm.hip
 
 // vk_order.hip: screen-space geometry of a camera, the tile order and its device ring
-void cull_rect_wh(uint32_t W, uint32_t H, const float *cam, int mode, int32_t r[4]);
 void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]);
 void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
                             uint32_t *order, uint32_t *order_pos, uint32_t &order_active, int G);

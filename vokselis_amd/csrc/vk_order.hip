@@ -14,160 +14,15 @@
 
 using namespace vk;
 
-// Screen-space bounding rectangle of the unit cube (NAIVE mode): the 8 corners projected with
-// proj_view in double; any corner at or behind the eye plane disables the cull.  Padded by 2 px.
-// Pixels outside [x0,x1) x [y0,y1) cannot hit the box.
-void cull_rect_wh(uint32_t W, uint32_t H, const float *cam, int mode, int32_t r[4]) {
-    r[0] = 0; r[1] = 0; r[2] = (int32_t)W; r[3] = (int32_t)H;
-    if (mode != VK_MODE_NAIVE_TRILINEAR) return;
-    const float *pv = cam + 4;
-    double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
-    for (int c = 0; c < 8; c++) {
-        const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
-        const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
-        const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
-        if (!(cw > 1e-6)) return;
-        const double sx = (cx / cw * 0.5 + 0.5) * W, sy = (0.5 - cy / cw * 0.5) * H;
-        x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
-    }
-    if (!(std::isfinite(x0) && std::isfinite(x1) && std::isfinite(y0) && std::isfinite(y1))) return;
-    r[0] = (int32_t)std::max(0.0, std::floor(x0) - 2.0);
-    r[1] = (int32_t)std::max(0.0, std::floor(y0) - 2.0);
-    r[2] = (int32_t)std::min((double)W, std::ceil(x1) + 2.0);
-    r[3] = (int32_t)std::min((double)H, std::ceil(y1) + 2.0);
-}
-void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]) { cull_rect_wh(ctx->width, ctx->height, cam, mode, r); }
+// The geometry itself -- cull rectangle, silhouette hull, tile_is_inactive, the heaviest-first order -- lives in vk_hostmath.hpp (pure C++:
+// tests/hostmath_fuzz.cpp runs it under -fsanitize=address,undefined); these are the context-shaped entry points the other TUs call.
+static_assert(vk::kModeNaive == VK_MODE_NAIVE_TRILINEAR, "vk_hostmath.hpp's mode constant");
+void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]) { vk::cull_rect_wh(ctx->width, ctx->height, cam, mode, r); }
 
-
-// The cube's silhouette on the screen: the convex hull of its 8 projected corners (counter-clockwise in screen
-// coordinates, y down), in double.  A pixel's ray hits the box only if the pixel centre lies inside it, so a tile that a
-// hull edge separates from it by more than 2 px holds only clear-colour pixels.  The bounding rectangle alone keeps
-// 288 of C2's 510 tiles; the hull keeps the ones a ray can actually hit.  n = 0: no hull (a corner behind the eye
-// plane, or another mode) -- the rectangle decides alone.
-struct CullHull { int n = 0; double x[16], y[16]; };
-static void cull_hull_wh(uint32_t W, uint32_t H, const float *cam, int mode, CullHull &h) {
-    h.n = 0;
-    if (mode != VK_MODE_NAIVE_TRILINEAR) return;
-    const float *pv = cam + 4;
-    std::pair<double, double> p[8];
-    for (int c = 0; c < 8; c++) {
-        const double X = c & 1, Y = (c >> 1) & 1, Z = (c >> 2) & 1;
-        const double cx = pv[0] * X + pv[4] * Y + pv[8] * Z + pv[12], cy = pv[1] * X + pv[5] * Y + pv[9] * Z + pv[13];
-        const double cw = pv[3] * X + pv[7] * Y + pv[11] * Z + pv[15];
-        if (!(cw > 1e-6)) return;
-        p[c] = {(cx / cw * 0.5 + 0.5) * W, (0.5 - cy / cw * 0.5) * H};
-        if (!(std::isfinite(p[c].first) && std::isfinite(p[c].second))) return;
-    }
-    std::sort(p, p + 8);
-    auto cross = [](const std::pair<double, double> &o, const std::pair<double, double> &a, const std::pair<double, double> &b) {
-        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
-    };
-    std::pair<double, double> hull[16];
-    int k = 0;
-    for (int i = 0; i < 8; i++) { while (k >= 2 && cross(hull[k - 2], hull[k - 1], p[i]) <= 0) k--; hull[k++] = p[i]; }
-    for (int i = 6, t = k + 1; i >= 0; i--) { while (k >= t && cross(hull[k - 2], hull[k - 1], p[i]) <= 0) k--; hull[k++] = p[i]; }
-    k--;  // (the last point repeats the first)
-    if (k < 3) return;  // degenerate (edge-on): the rectangle decides
-    h.n = k;
-    for (int i = 0; i < k; i++) { h.x[i] = hull[i].first; h.y[i] = hull[i].second; }
-}
-// (forward) the tile-level decision, shared by the tile order and vk_tiles_active
-static bool tile_is_inactive(const int32_t cr[4], const CullHull &hull, int64_t x0, int64_t y0, uint32_t ts);
-
-// true when some hull edge has the whole rectangle [x0,x1] x [y0,y1] more than `pad` pixels on its outer side
-static bool hull_separates(const CullHull &h, double x0, double y0, double x1, double y1, double pad) {
-    for (int i = 0; i < h.n; i++) {
-        const int j = i + 1 == h.n ? 0 : i + 1;
-        const double ex = h.x[j] - h.x[i], ey = h.y[j] - h.y[i];
-        const double len = std::sqrt(ex * ex + ey * ey);
-        if (!(len > 0)) continue;
-        // monotone chain with this cross-product sign walks the hull with its interior on the left: d < 0 is outside
-        const double nx = -ey, ny = ex;  // left normal
-        const double d0 = nx * (x0 - h.x[i]) + ny * (y0 - h.y[i]), d1 = nx * (x1 - h.x[i]) + ny * (y0 - h.y[i]);
-        const double d2 = nx * (x0 - h.x[i]) + ny * (y1 - h.y[i]), d3 = nx * (x1 - h.x[i]) + ny * (y1 - h.y[i]);
-        if (std::max(std::max(d0, d1), std::max(d2, d3)) < -pad * len) return true;
-    }
-    return false;
-}
-
-static bool tile_is_inactive(const int32_t cr[4], const CullHull &hull, int64_t x0, int64_t y0, uint32_t ts) {
-    return x0 + ts <= cr[0] || x0 >= cr[2] || y0 + ts <= cr[1] || y0 >= cr[3] ||
-           (hull.n && hull_separates(hull, (double)x0, (double)y0, (double)(x0 + ts), (double)(y0 + ts), 2.0));
-}
-
-// Tiles are dealt to the launch (and, at N > 1, to the ranks) heaviest first.  The frame is ~70 %
-// empty and a dense ray ends after 2 steps while a grazing one takes 513, so with ~10 working waves
-// per SIMD the kernel's tail is set by whichever heavy tiles start last; starting them first (and
-// round-robining them over ranks) shortens it.  The cost estimate is the nominal step count of a
-// 3x3 grid of rays per tile, from the same camera maths as the kernel, in double precision on the
-// host.  It is only a launch order: every tile is rendered by the same kernel whatever its rank.
 void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
-                                   uint32_t *order, uint32_t *order_pos, uint32_t &order_active, int G) {
-    const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
-    const size_t n = (size_t)tx * ty;
-    const double W = ctx->width, H = ctx->height;
-    // tiles that do not touch the cube's screen rectangle hold only clear-colour pixels: they sort last (in index
-    // order) and are "inactive" -- never marched, never gathered (the root clears them in vk_untile); no rays for them
-    int32_t cr[4];
-    cull_rect_cam(ctx, cam, mode, cr);
-    CullHull hull;
-    cull_hull_wh(ctx->width, ctx->height, cam, mode, hull);
-    struct Key { double cost; uint32_t tile; };
-    std::vector<Key> act;
-    act.reserve(n);
-    const float *m = cam + 20;
-    const double dims[3] = {(double)std::max(ctx->nx, 1u), (double)std::max(ctx->ny, 1u), (double)std::max(ctx->nz, 1u)};
-    uint32_t n_inactive = 0;
-    for (uint32_t j = 0; j < ty; j++)
-        for (uint32_t i = 0; i < tx; i++) {
-            const int64_t x0 = (int64_t)ox + (int64_t)i * ts, y0 = (int64_t)oy + (int64_t)j * ts;
-            const uint32_t tile = j * tx + i;
-            if (tile_is_inactive(cr, hull, x0, y0, ts)) { order[n - 1 - n_inactive++] = tile; continue; }  // (reversed below)
-            double c = 0.0;
-            for (int sy = 0; sy < G; sy++)
-                for (int sx = 0; sx < G; sx++) {
-                    const double px = (double)x0 + (2 * sx + 1) * ts / (2.0 * G), py = (double)y0 + (2 * sy + 1) * ts / (2.0 * G);
-                    if (px < 0 || py < 0 || px >= W || py >= H) continue;
-                    double e[3], d[3], lo, hi;
-                    if (mode == VK_MODE_NAIVE_TRILINEAR) {
-                        const double X = 2.0 * px / W - 1.0, Y = 1.0 - 2.0 * py / H;
-                        const double qw = 1.0 / (m[3] * X + m[7] * Y + m[11] + m[15]);
-                        for (int k = 0; k < 3; k++) { e[k] = cam[k]; d[k] = (m[k] * X + m[4 + k] * Y + m[8 + k] + m[12 + k]) * qw - e[k]; }
-                        lo = 0.0; hi = 1.0;
-                    } else {
-                        const double X = 2.0 * px / W - 1.0, Y = (2.0 * py / H - 1.0) * -(H / W);
-                        const double aw = 1.0 / (m[3] * X + m[7] * Y + m[15]), bw = 1.0 / (m[3] * X + m[7] * Y + m[11] + m[15]);
-                        for (int k = 0; k < 3; k++) {
-                            e[k] = (m[k] * X + m[4 + k] * Y + m[12 + k]) * aw;
-                            d[k] = (m[k] * X + m[4 + k] * Y + m[8 + k] + m[12 + k]) * bw - e[k];
-                        }
-                        lo = -1.0; hi = 1.0;
-                    }
-                    const double len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-                    if (!(len2 > 0)) continue;
-                    // steps = (t1 - t0) / dt with t in units of |d| (the normalisation cancels): dt = min_k 1 / (dims_k |d_k|)
-                    double t0 = -1e300, t1 = 1e300, inv_dt = 0.0;
-                    for (int k = 0; k < 3; k++) {
-                        const double inv = 1.0 / d[k], ta = (lo - e[k]) * inv, tb = (hi - e[k]) * inv;
-                        t0 = std::max(t0, std::min(ta, tb));
-                        t1 = std::min(t1, std::max(ta, tb));
-                        inv_dt = std::max(inv_dt, dims[k] * std::fabs(d[k]));
-                    }
-                    t0 = std::max(t0, 0.0);
-                    if (t1 > t0 && inv_dt > 0) c += (t1 - t0) * inv_dt;
-                }
-            act.push_back({c, tile});
-        }
-    const uint32_t n_active = (uint32_t)act.size();
-    std::stable_sort(act.begin(), act.end(), [](const Key &a, const Key &b) { return a.cost > b.cost; });
-    for (uint32_t q = 0; q < n_active; q++) order[q] = act[q].tile;
-    std::reverse(order + n_active, order + n);  // inactive tiles in index order
-    // Position q goes to XCD q % 8 (rank q % N first, when the frame is partitioned): dealt straight, bin 0
-    // would receive the heaviest tile of every round of 8.  Reverse every other round (snake) so the bins'
-    // sums even out; the active tiles stay in front.
-    for (size_t g = 8; g + 8 <= n_active; g += 16) std::reverse(order + g, order + g + 8);
-    order_active = n_active;
-    for (size_t q = 0; q < n; q++) order_pos[order[q]] = (uint32_t)q;
+                            uint32_t *order, uint32_t *order_pos, uint32_t &order_active, int G) {
+    const uint32_t dims[3] = {ctx->nx, ctx->ny, ctx->nz};
+    vk::tile_order(ctx->width, ctx->height, dims, cam, mode, ox, oy, rw, rh, ts, order, order_pos, order_active, G);
 }
 
 static void compute_tile_order(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,

@@ -34,8 +34,7 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
     const uint32_t *d_pos = ctx->d_order_pos;
     const uint32_t n_active = ctx->order_active;
     const uint32_t n_slots = slot_stride;  // slots per rank in `gathered`
-    const uint32_t chunks = (tile_size * tile_size + 511u) / 512u;
-    const uint64_t blocks = (uint64_t)n_tiles * chunks;
+    const uint64_t blocks = untile_blocks(tile_size, (uint32_t)n_tiles, 1u);
     if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile: too many tiles for one launch");
     const uint32_t rs = nranks > 1 ? ctx->root_skip : 0u;
     if (ctx->out_format == VK_OUT_RGBA16F)
@@ -103,14 +102,13 @@ int vk_untile_batch_over(vk_ctx *ctx, uint32_t batch_id, const void *gathered, u
               P->out_format != B->out_format || !P->d)) P = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t tx = (ctx->width + B->ts - 1) / B->ts;
-    const uint32_t chunks = (B->ts * B->ts + 511u) / 512u;
-    const uint64_t blocks = (uint64_t)B->n_frames * B->n_tiles * chunks;
+    const uint64_t blocks = untile_blocks(B->ts, B->n_tiles, B->n_frames);
     if (blocks >= (1ull << 31)) return fail(ctx, VK_ERR_UNSUPPORTED, "vk_untile_batch: too many tiles for one launch");
     const FrameDesc *frames = reinterpret_cast<const FrameDesc *>(B->d);
-    const uint32_t *pos = reinterpret_cast<const uint32_t *>(B->d + (size_t)B->n_frames * sizeof(FrameDesc)) + (size_t)B->n_frames * B->n_tiles;
+    const uint32_t *pos = reinterpret_cast<const uint32_t *>(B->d + batch_order_offset(B->n_frames, sizeof(FrameDesc))) + (size_t)B->n_frames * B->n_tiles;
     // FrameDesc::n_active of a compact batch is the frame's active tile count (what the gather carried)
     const FrameDesc *pframes = P ? reinterpret_cast<const FrameDesc *>(P->d) : nullptr;
-    const uint32_t *ppos = P ? reinterpret_cast<const uint32_t *>(P->d + (size_t)P->n_frames * sizeof(FrameDesc)) + (size_t)P->n_frames * P->n_tiles : nullptr;
+    const uint32_t *ppos = P ? reinterpret_cast<const uint32_t *>(P->d + batch_order_offset(P->n_frames, sizeof(FrameDesc))) + (size_t)P->n_frames * P->n_tiles : nullptr;
     if (ctx->out_format == VK_OUT_RGBA16F)
         hipLaunchKernelGGL(untile_batch_kernel<OUT_RGBA16F>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, gathered, out_frames, ctx->width, ctx->height, B->ts, tx, B->n_tiles, B->nranks, n_slots, B->n_frames, pos, frames, B->root_skip, 0u, ppos, pframes, (uint32_t)B->wire);
     else

@@ -65,20 +65,15 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
                                                            const uint32_t *__restrict__ tile_pos, const FrameDesc *__restrict__ frames, uint32_t root_skip,
                                                            uint32_t n_active_one, const uint32_t *__restrict__ prev_tile_pos = nullptr,
                                                            const FrameDesc *__restrict__ prev_frames = nullptr, uint32_t wire_rgb = 0u) {
-    const uint32_t chunks = (ts * ts + 511u) / 512u;  // 512-pixel chunks per tile
-    uint32_t b = blockIdx.x;
-    const uint32_t chunk = b % chunks; b /= chunks;
-    const uint32_t tile = b % n_tiles;
-    const uint32_t frame = b / n_tiles;
-    if (frame >= n_frames) return;
-    const uint32_t l = chunk * 512u + threadIdx.x * 2u;  // first of this lane's two pixels inside the tile (ts is even)
-    if (l >= ts * ts) return;
+    const UntileItem it = untile_item(blockIdx.x, threadIdx.x, ts, n_tiles, n_frames);  // (vk_hostmath.hpp: the map tests/hostmath_fuzz.cpp replays)
+    if (!it.in_range) return;
+    const uint32_t tile = it.tile, frame = it.frame, l = it.l;
     const uint32_t ly = l / ts, lx = l - ly * ts;
     const uint32_t tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const uint32_t x = txi * ts + lx, y = tyi * ts + ly;
     if (x >= W || y >= H) return;
     const bool two = x + 1u < W;  // W odd: the last pixel of a row stands alone
-    const size_t dst = ((size_t)frame * H + y) * W + x;
+    const size_t dst = frame_pixel_index(frame, W, H, x, y);
     const uint32_t pos = tile_pos[(size_t)frame * n_tiles + tile];
     const uint32_t n_active = frames ? frames[frame].n_active : n_active_one;
     if (pos >= n_active) {  // the box's silhouette cannot reach this tile: never marched, never gathered
@@ -90,9 +85,9 @@ __global__ __launch_bounds__(256) void untile_batch_kernel(const void *__restric
     }
     uint32_t rank, slot;
     deal_owner(pos, nranks, root_skip, rank, slot);
-    const size_t src = ((((size_t)rank * n_slots + slot) * n_frames + frame) * ts + ly) * ts + lx;
+    const size_t src = gathered_pixel_index(rank, n_slots, slot, n_frames, frame, ts, lx, ly);
     if (wire_rgb) {  // records of ts*ts (r, g) pairs + ts*ts b values (store_out): alpha is 1
-        const size_t tt = (size_t)ts * ts, rec = ((size_t)rank * n_slots + slot) * n_frames + frame;
+        const size_t tt = (size_t)ts * ts, rec = gathered_record(rank, n_slots, slot, n_frames, frame);
         if (OUT == OUT_RGBA32F) {
             const float *g = reinterpret_cast<const float *>(gathered) + rec * tt * 3u;
             const float4 rg = *reinterpret_cast<const float4 *>(g + 2u * l);  // (l even: 16-byte aligned)

@@ -85,6 +85,12 @@ def n_slots(width: int, height: int, tile_size: int, world: int, root_skip: int 
     return deal_rounds(tx * ty, world, root_skip)
 
 
+class PeerLostError(RuntimeError):
+    """A gather did not complete: a peer has gone (its process ended, its GPU hung) or the wire is stuck.  Raised on the surviving ranks
+    within the renderer's time limit instead of leaving them parked inside a collective; the library communicator, if any, has been
+    aborted (vk_comm_abort), so the process can report and leave -- a retry belongs to a NEW job (fresh processes, a fresh rendezvous)."""
+
+
 class TorchTileGather:
     """The collective through torch.distributed: every rank's [n, B, ts, ts, 4] prefix to the root's
     [world, n, B, ts, ts, 4].  Device-agnostic (gloo for CPU tensors, RCCL for cuda tensors); `via_host` stages
@@ -96,20 +102,33 @@ class TorchTileGather:
         self.dist, self.group, self.root, self.via_host = dist, group, root, via_host
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
-    def gather(self, send, recv, root=None):
-        """send: tensor [n, B, ...]; recv (on the root): tensor [world, n, B, ...].  Blocking.  `root`: this gather's destination
-        (default: the one given at construction)."""
+    def _gather(self, send, out, root, timeout_s):
+        """dist.gather with a time limit: a peer that is gone makes it fail (gloo: connection closed) or never finish (timeout)."""
+        import datetime
+
+        try:
+            work = self.dist.gather(send, gather_list=out, dst=root, group=self.group, async_op=True)
+            if timeout_s is None:
+                work.wait()
+            else:
+                work.wait(datetime.timedelta(seconds=float(timeout_s)))
+        except Exception as e:  # noqa: BLE001  (torch raises RuntimeError / DistBackendError here, with backend-specific texts)
+            raise PeerLostError("rank %d: the tile gather to rank %d failed or did not finish within %s s: %s" % (self.rank, root, timeout_s, str(e)[:300])) from e
+
+    def gather(self, send, recv, root=None, timeout_s=None):
+        """send: tensor [n, B, ...]; recv (on the root): tensor [world, n, B, ...].  Blocking, for at most `timeout_s` seconds (None: no
+        limit); PeerLostError when it fails or runs out of time.  `root`: this gather's destination (default: the one given at construction)."""
         root = self.root if root is None else root
         if self.via_host:
             s = send.cpu()
             out = [s.new_empty(s.shape) for _ in range(self.world)] if self.rank == root else None
-            self.dist.gather(s, gather_list=out, dst=root, group=self.group)
+            self._gather(s, out, root, timeout_s)
             if self.rank == root:
                 for r in range(self.world):
                     recv[r].copy_(out[r])
             return
         out = [recv[r] for r in range(self.world)] if self.rank == root else None
-        self.dist.gather(send, gather_list=out, dst=root, group=self.group)
+        self._gather(send, out, root, timeout_s)
 
 
 class BatchTileRenderer:
@@ -126,11 +145,15 @@ class BatchTileRenderer:
     56 directed links of the node -- for consumers that are themselves per GPU (an encoder, a NIC), not for a window on GPU 0."""
 
     def __init__(self, ctx: Context, pipeline: RaycastPipeline, tile_size: int = 64, batch: int = 16, root: int = 0, group=None,
-                 transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto", wire: int = N.WIRE_RGB):
+                 transport: str = "rccl", on_batch=None, via_host: bool = False, root_skip="auto", wire: int = N.WIRE_RGB, timeout_s: float | None = 120.0):
         import torch
         import torch.distributed as dist
 
         self.torch = torch
+        # Time limit of every wait on a gather (PeerLostError beyond it; None: wait for ever, the behaviour before round 6).  A gather of one
+        # batch takes milliseconds: the limit only has to be longer than a peer's slowest march of a batch.
+        self.timeout_s = timeout_s
+        self._dead = False
         self.rotate = root == "rotate"
         root = 0 if self.rotate else int(root)
         self.ctx, self.pipe, self.ts, self.batch, self.root = ctx, pipeline, tile_size, max(1, int(batch)), root
@@ -289,7 +312,34 @@ class BatchTileRenderer:
         if len(self._cams) == self.batch:
             self._launch()
 
+    def _lost(self, what: str):
+        """The survivor's way out: abort the library communicator (never destroy it: that waits for the dead transfer), mark the renderer
+        dead, raise.  The caller reports and ends the process."""
+        self._dead = True
+        if self.transport == "rccl":
+            try:
+                N.lib().vk_comm_abort(self.ctx.handle)
+            except Exception:  # noqa: BLE001
+                pass
+        raise PeerLostError("rank %d: %s did not complete within %s s -- a peer is gone or its gather is stuck; the communicator has been aborted" % (self.rank, what, self.timeout_s))
+
+    def _wait_event(self, ev, what: str):
+        """Host-side wait for a cuda event with the renderer's time limit (a stream-side wait on a gather that never completes would park
+        every later launch behind it, and the host in the library's next blocking call)."""
+        import time
+
+        if self.timeout_s is None:
+            ev.synchronize()
+            return
+        t_end = time.monotonic() + float(self.timeout_s)
+        while not ev.query():
+            if time.monotonic() > t_end:
+                self._lost(what)
+            time.sleep(2e-4)
+
     def _launch(self):
+        if self._dead:
+            raise PeerLostError("rank %d: this renderer lost a peer earlier; start a new job" % self.rank)
         with self.torch.cuda.stream(self.march_stream):
             self._launch_on_stream()
 
@@ -299,6 +349,7 @@ class BatchTileRenderer:
         if len(cams) < self.batch:  # a partial batch marches (and moves) whole batches: pad with the last camera
             cams = cams + [cams[-1]] * (self.batch - len(cams))
         if self._used[s]:
+            self._wait_event(self.moved[s], "the gather of two batches ago")  # (bounded, on the host: normally long done)
             self.march_stream.wait_event(self.moved[s])  # the set's previous gather has read its tiles
         # Rank 0's share of a gather to rank 0 sits at the very start of the receive buffer whatever the active-slot count turns out to be: it
         # marches straight into it (vk_gather_tiles then finds send == its own segment and copies nothing -- at a world of one that copy was
@@ -323,7 +374,11 @@ class BatchTileRenderer:
             self.marched[s].synchronize()
             if act > 0:
                 recv = self.recv[s][: self.world * act * self.batch].view(self.world, act, self.batch, self.tile_elems) if mine else None
-                self.tg.gather(self.send[s][:act], recv, root)
+                try:
+                    self.tg.gather(self.send[s][:act], recv, root, self.timeout_s)
+                except PeerLostError:
+                    self._dead = True
+                    raise
             self.moved[s].record(self.march_stream)
         self._used[s] = True
         # the previous batch is on the root by now (its gather overlapped this march): un-tile and deliver it
@@ -339,6 +394,8 @@ class BatchTileRenderer:
         self._pending = None
         if self.rank != root:
             return
+        # (a stream-side wait: the host goes on preparing the next batch while this gather is on the wire.  A gather that never completes is
+        # found by the bounded host-side wait on this set's `moved` event at the launch two batches on, or by flush().)
         self.march_stream.wait_event(self.moved[s])
         # frames[s] still holds what this object un-tiled into it two batches ago: only tiles whose state changed are cleared
         untile_batch(self.ctx, bid, self.recv[s].data_ptr(), act, self.frames[s].data_ptr(), prev_batch_id=self._frames_bid[s])
@@ -347,12 +404,25 @@ class BatchTileRenderer:
             self.on_batch(first, count, self.frames[s][:count])
 
     def flush(self):
+        """Launch a partial batch, deliver what is pending and wait -- for at most `timeout_s` per wait -- until this rank's part of every
+        gather is through.  PeerLostError when a peer is gone."""
+        if self._dead:
+            raise PeerLostError("rank %d: this renderer lost a peer earlier; start a new job" % self.rank)
         if self._cams:
             self._launch()
         with self.torch.cuda.stream(self.march_stream):
             self._finish_pending()
+        for s in (0, 1):  # a non-root rank's sends, and whatever the un-tile left on the march stream
+            if self._used[s]:
+                self._wait_event(self.moved[s], "a gather")
+        done = self.torch.cuda.Event()
+        done.record(self.march_stream)
+        self._wait_event(done, "the un-tile behind the last gather")
 
     def close(self):
+        if self._dead:  # nothing to drain: the communicator is gone; give the context its wire format back and leave
+            self.ctx.set_wire(self._wire_before)
+            return
         self.flush()
         if self.transport == "rccl":
             self.torch.cuda.synchronize()
