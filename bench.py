@@ -594,20 +594,48 @@ def main():
                 btr.flush()
                 btr_i[0] = 0
 
+        region_no = [0]
+        # N > 1: a window is full of collectives, and a rank whose peer is gone would sit in one of them for ever (RCCL has no time limit of its
+        # own here; torch's watchdog takes ten minutes).  Every window therefore runs under a limit: a rank still inside it after
+        # VK_BENCH_WINDOW_LIMIT_S seconds (default 240; a window is a fraction of a second) says so and ends its process with a non-zero
+        # code -- which ends the job through the launcher.  No retry from inside: a process that has touched the GPU is never re-executed.
+        window_limit_s = float(os.environ.get("VK_BENCH_WINDOW_LIMIT_S", "240"))
+
+        def window_overrun():
+            print("[bench] rank %d: a window of the N = %d run did not complete within %.0f s (a peer gone, or a gather stuck): ending this rank"
+                  % (rank, world, window_limit_s), file=sys.stderr, flush=True)
+            os._exit(74)
+
         def timed_region(k, timed):
-            torch.cuda.synchronize()
+            region_no[0] += 1
+            if world > 1 and os.environ.get("VK_BENCH_TEST_END_RANK", "") == str(rank) and region_no[0] == 3:
+                # TEST HOOK (tests/test_peer_loss_gpu.py): this rank's process ends here, without a word to its peers -- a rank that died
+                print("[bench] VK_BENCH_TEST_END_RANK: rank %d ends before window %d" % (rank, region_no[0]), file=sys.stderr, flush=True)
+                os._exit(0)
+            guard = None
             if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                submit(timed)
-            flush(timed)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
+                import threading
+
+                guard = threading.Timer(window_limit_s, window_overrun)
+                guard.daemon = True
+                guard.start()
+            try:
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    submit(timed)
+                flush(timed)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            finally:
+                if guard is not None:
+                    guard.cancel()
             if world > 1:
                 tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -86,14 +86,16 @@ def test_stuck_gather_on_the_library_communicator_is_aborted(V):
         assert len(got) == 1
         want = got[0].cpu().numpy()
         # the "peer that never answers": the stream the gather runs on spins for seconds
+        # (a spinning kernel of ~2 s.  Unlike an RCCL kernel waiting for a dead peer it cannot be told to stop, and ncclCommAbort drains the
+        # device: the error arrives when the spin ends at the latest -- the bound asserted here -- and at the time limit when the wait is RCCL's)
         with torch.cuda.stream(btr.comm_stream):
-            torch.cuda._sleep(int(12e9))
+            torch.cuda._sleep(int(5e9))
         t0 = time.monotonic()
         with pytest.raises(PeerLostError):
             for c in cams:
                 btr.submit(c)
             btr.flush()
-        assert time.monotonic() - t0 < 3.0
+        assert 0.45 < time.monotonic() - t0 < 4.0
         rank, nranks = V.native.C.c_int(-1), V.native.C.c_int(-1)
         V.native.check(ctx.handle, V.native.lib().vk_comm_info(ctx.handle, V.native.C.byref(rank), V.native.C.byref(nranks)))
         assert nranks.value == 0  # aborted: no communicator left
