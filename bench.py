@@ -1003,6 +1003,15 @@ def main():
                                                      "bound": "valu (f64)", "f64_T_lane_ops_per_s": f64_rate / 1e12, "f64_frac_of_vector_peak": f64_rate / F64_LANE_OPS_PEAK,
                                                      "valu_frac_floor": valu_floor_frac(sr, 952, 3.77, ms),
                                                      "valu_frac_pmc": "0.80 (profiles/r03_utilisation.txt; 112 VGPRs: 4 waves per SIMD)", "volume_bytes_per_step": 0}
+                    # beside it, what the chip does with the shader AS WRITTEN: hash()'s sine through v_sin_f32 (VK_RENDER_DEVICE_SINE, a tolerance
+                    # mode: another noise field of the same statistics -- tests/test_frames_gpu.py holds the bars)
+                    pdv = V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_DEVICE_SINE)
+                    ms_d = time_launches(cp, lambda: pdv.record(cp), 10, warm=2)
+                    extras["c3_procedural_1080p"]["device_sine"] = {
+                        "launch_ms": ms_d, "Mray_steps_per_s_at_specified_step_count": sr / ms_d / 1e3, "speedup": ms / ms_d,
+                        "note": "tolerance mode, NOT the specified arithmetic: hash = fract(sin(h) * 43758.5) with the hardware sine (v_sin_f32 after * 1/2pi and fract) "
+                                "as a GPU running shaders/xor.wgsl:18-20 as written computes it; against the specified frame: mean |d| 0.017, max 0.17, mean colour "
+                                "within 0.3 %, 8x8-blurred correlation 0.986 (tools/c3_device_sine.py)"}
                 finally:
                     cp.close()
             except Exception as e:

@@ -330,3 +330,44 @@ def test_present_fused_misuse_and_frames_in_flight(V):
             V.render_batch(ctx, V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=DT, flags=V.RENDER_PRESENT_ONLY), [cams[0]], buf.data_ptr())
     finally:
         ctx.close()
+
+
+# ---- C3 with the device's own sine (VK_RENDER_DEVICE_SINE): a tolerance mode with stated bars ---------------------------------------------
+
+
+def test_procedural_device_sine_tolerance_mode(V, O):
+    """What a GPU running xor.wgsl as written computes -- hash = fract(sin(h) * 43758.5) with the HARDWARE sine -- beside the specified sine the
+    oracle shares.  The hash amplifies the sine's error at arguments up to ~8e5 into a different noise field, so nothing is compared pixel by
+    pixel; the bars are statistical: the same frame in the large (8 x 8-blurred correlation >= 0.95, mean colour of the lit pixels within 2 %),
+    mean |d| <= 0.05, and every pixel whose ray misses the box clear-coloured in both.  The specified march stays the one held to the oracle."""
+    W, H = 1920, 1080
+    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix()
+    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
+    try:
+        ctx.set_camera_blob(cam)
+        ctx.reset_step_counts()
+        V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_COUNT).record(ctx)
+        spec, steps = ctx.read_backbuffer(), ctx.read_steps()
+        V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_DEVICE_SINE).record(ctx)
+        dev = ctx.read_backbuffer()
+        with pytest.raises(V.VokselisError):
+            V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_DEVICE_SINE | V.RENDER_COUNT).record(ctx)
+    finally:
+        ctx.close()
+    # the specified march is the oracle's (a tile of it, here; the whole frame in test_procedural_full_size_tiles)
+    tile = (W // 2 - 32, H // 2 - 32, 64, 64)
+    ref, rsteps = O.render_procedural(cam, W, H, tile=tile)
+    sl = (slice(tile[1], tile[1] + 64), slice(tile[0], tile[0] + 64))
+    assert (steps[sl] == rsteps[sl]).all() and np.abs(spec[sl] - ref[sl]).max() <= TOL
+    clear = np.array([0.023, 0.02, 0.02, 1.0], np.float32)
+    miss = steps == 0
+    assert (spec[miss] == clear).all() and (dev[miss] == clear).all() and (dev[..., 3] == 1).all()
+    lit = (spec[..., :3] != clear[:3]).any(-1)
+    assert 0.05 < lit.mean() < 0.2
+    d = np.abs(spec - dev)[..., :3]
+    assert d[lit].mean() <= 0.05 and d.max() < 0.5, (d[lit].mean(), d.max())
+    assert d.max() > 1e-3  # (it IS another noise field: a frame equal to the specified one would mean the flag did nothing)
+    ms, md = spec[lit][:, :3].mean(0), dev[lit][:, :3].mean(0)
+    assert np.abs(md / ms - 1.0).max() <= 0.02, (ms, md)
+    blur = lambda im: im[..., 0].reshape(H // 8, 8, W // 8, 8).mean((1, 3)).ravel()
+    assert np.corrcoef(blur(spec), blur(dev))[0, 1] >= 0.95

@@ -12,7 +12,7 @@ from . import _native as native
 from . import volumes
 from ._native import (FMT_R8_UNORM, FMT_R16_FLOAT, FMT_RGBA16F_PAIR, LAYOUT_AUTO, LAYOUT_LINEAR, LAYOUT_PACKED, LAYOUT_PACKED_PAIRS, LAYOUT_BRICKED, LAYOUT_QUADS, LAYOUT_STAGED, RENDER_SAFE, RENDER_FORCE_SKIP,
                       GEN_BONSAI_STANDIN, GEN_FOG, GEN_FOG_DENSE_CORE, MODE_COMPUTE_NEAREST, MODE_NAIVE_TRILINEAR, MODE_PROCEDURAL, OUT_RGBA16F, OUT_RGBA32F, RENDER_COUNT,
-                      RENDER_NO_SKIP, RENDER_PROBE_ALWAYS, RENDER_FAST_WALK, RENDER_PRESENT, RENDER_PRESENT_BGRA, RENDER_PRESENT_ONLY, WIRE_RGB, WIRE_RGBA, VokselisError)
+                      RENDER_NO_SKIP, RENDER_PROBE_ALWAYS, RENDER_FAST_WALK, RENDER_PRESENT, RENDER_PRESENT_BGRA, RENDER_PRESENT_ONLY, RENDER_DEVICE_SINE, WIRE_RGB, WIRE_RGBA, VokselisError)
 from .camera import Camera
 from .context import (Context, Demo, FrameCounter, HdrBackBuffer, ImageDimentions, RaycastPipeline, Uniform,
                       VolumeTexture, dispatch_optimal, partition_slots, render_batch, run_headless, untile_batch)
@@ -21,5 +21,5 @@ __all__ = [
     "native", "volumes", "GEN_BONSAI_STANDIN", "GEN_FOG", "GEN_FOG_DENSE_CORE", "Camera", "Context", "Demo", "FrameCounter", "HdrBackBuffer", "ImageDimentions", "RaycastPipeline",
     "Uniform", "VolumeTexture", "dispatch_optimal", "partition_slots", "render_batch", "untile_batch", "run_headless", "VokselisError",
     "FMT_R8_UNORM", "FMT_R16_FLOAT", "FMT_RGBA16F_PAIR", "LAYOUT_AUTO", "LAYOUT_LINEAR", "LAYOUT_PACKED", "LAYOUT_PACKED_PAIRS", "LAYOUT_BRICKED", "LAYOUT_QUADS", "LAYOUT_STAGED", "RENDER_SAFE", "RENDER_FORCE_SKIP",
-    "MODE_COMPUTE_NEAREST", "MODE_NAIVE_TRILINEAR", "MODE_PROCEDURAL", "OUT_RGBA16F", "OUT_RGBA32F", "RENDER_COUNT", "RENDER_NO_SKIP", "RENDER_PROBE_ALWAYS", "RENDER_FAST_WALK", "RENDER_PRESENT", "RENDER_PRESENT_BGRA", "RENDER_PRESENT_ONLY", "WIRE_RGB", "WIRE_RGBA",
+    "MODE_COMPUTE_NEAREST", "MODE_NAIVE_TRILINEAR", "MODE_PROCEDURAL", "OUT_RGBA16F", "OUT_RGBA32F", "RENDER_COUNT", "RENDER_NO_SKIP", "RENDER_PROBE_ALWAYS", "RENDER_FAST_WALK", "RENDER_PRESENT", "RENDER_PRESENT_BGRA", "RENDER_PRESENT_ONLY", "RENDER_DEVICE_SINE", "WIRE_RGB", "WIRE_RGBA",
 ]

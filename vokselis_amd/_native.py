@@ -19,6 +19,7 @@ RENDER_NO_SKIP, RENDER_COUNT, RENDER_SAFE, RENDER_FORCE_SKIP = 1, 2, 4, 8
 RENDER_DEBUG_TRIPS = 16
 RENDER_DEBUG_FALLBACK, RENDER_PROBE_ALWAYS, RENDER_FAST_WALK = 32, 64, 128
 RENDER_PRESENT, RENDER_PRESENT_BGRA, RENDER_PRESENT_ONLY = 256, 512, 1024
+RENDER_DEVICE_SINE = 2048
 WIRE_RGBA, WIRE_RGB = 0, 1
 MAX_FRAMES_IN_FLIGHT = 4
 GEN_FOG, GEN_BONSAI_STANDIN, GEN_FOG_DENSE_CORE = 0, 1, 2

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(64) void raymarch_compute_kernel(const LaunchDesc L
 // example's density function at the sample position, noise_volume(p / 2) (shaders/xor.wgsl:55-61), colour =
 // density.rgb / 2, no normals -- mirrors pixel_procedural of the oracle operation for operation.  No volume,
 // no loads: 24 specified sines (f64 Cody-Waite, ~45 f64 operations each) and ~200 f32 flops per step.
-template <int OUT, bool COUNT>
+// DEVSIN: the hash's sine is the hardware's (VK_RENDER_DEVICE_SINE, a tolerance mode: vk_xor.hpp) instead of the specified one.
+template <int OUT, bool COUNT, bool DEVSIN = false>
 __global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDesc L, float time) {
     const uint32_t lb = logical_block(blockIdx.x);
     if (lb >= L.n_blocks) return;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64) void raymarch_procedural_kernel(const LaunchDes
         for (float t = t0; t < t1; t = t + dt) {
             const float px = eye[0] + t * dir[0], py = eye[1] + t * dir[1], pz = eye[2] + t * dir[2];
             float val, alpha;
-            xor_noise_volume(px * 0.5f, py * 0.5f, pz * 0.5f, off1, val, alpha);
+            xor_noise_volume<DEVSIN>(px * 0.5f, py * 0.5f, pz * 0.5f, off1, val, alpha);
             n_iter++;
             const float vc = val / 2.0f;
             float va = (alpha * alpha) * alpha;

@@ -196,4 +196,4 @@ uint32_t launch_flags(const vk_ctx *ctx, uint32_t render_flags, bool batch);
 void launch_cells(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool skip, bool safe, int walk /* vk_march.hpp: WalkKind */);
 void launch_staged(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, const float *cam);
 void launch_compute(vk_ctx *ctx, const vk::LaunchDesc &L, const vk::VolumeDesc &V, uint32_t grid, bool count, bool records, bool skip);
-void launch_procedural(vk_ctx *ctx, const vk::LaunchDesc &L, uint32_t grid, bool count, float time);
+void launch_procedural(vk_ctx *ctx, const vk::LaunchDesc &L, uint32_t grid, bool count, float time, bool device_sine);

@@ -4,8 +4,13 @@
 
 using namespace vk;
 
-void launch_procedural(vk_ctx *ctx, const LaunchDesc &L, uint32_t grid, bool count, float time) {
+void launch_procedural(vk_ctx *ctx, const LaunchDesc &L, uint32_t grid, bool count, float time, bool device_sine) {
     const bool f16 = ctx->out_format == VK_OUT_RGBA16F;
+    if (device_sine) {  // (tolerance mode: no counting instantiation of its own -- the counters describe the specified march)
+        if (f16) hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA16F, false, true>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+        else hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA32F, false, true>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
+        return;
+    }
     if (f16) {
         if (count) hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA16F, true>), dim3(grid), dim3(64), 0, ctx->stream, L, time);
         else hipLaunchKernelGGL((raymarch_procedural_kernel<OUT_RGBA16F, false>), dim3(grid), dim3(64), 0, ctx->stream, L, time);

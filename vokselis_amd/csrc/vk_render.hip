@@ -81,7 +81,8 @@ int dispatch_march(vk_ctx *ctx, int mode, const LaunchDesc &L_in, uint32_t flags
         float time = 0.0f;
         std::memcpy(&time, ctx->uniform + 36, sizeof(float));  // Uniform.time (global_ubo.rs:52-65), what xor.wgsl reads as un.time
         if (!std::isfinite(time)) return fail(ctx, VK_ERR_INVALID, "Uniform.time must be finite");
-        launch_procedural(ctx, L, grid, count, time);
+        if ((flags & VK_RENDER_DEVICE_SINE) && count) return fail(ctx, VK_ERR_INVALID, "VK_RENDER_DEVICE_SINE is a tolerance mode: count steps with the specified sine");
+        launch_procedural(ctx, L, grid, count, time, (flags & VK_RENDER_DEVICE_SINE) != 0);
     } else if (mode == VK_MODE_COMPUTE_NEAREST) {
         launch_compute(ctx, L, V, grid, count, ctx->vol_kind == VOL_PAIRB, !(flags & VK_RENDER_NO_SKIP));  // bricked 16-byte records, or the two dense volumes (the literal twin)
     } else {

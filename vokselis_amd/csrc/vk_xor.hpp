@@ -57,26 +57,35 @@ __device__ __forceinline__ float sin_spec(float h) {
 }
 __device__ __forceinline__ float xor_fract(float x) { return x - floorf(x); }
 __device__ __forceinline__ float xor_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
-__device__ __forceinline__ float xor_hash(float h) { return xor_fract(sin_spec(h) * 43758.5453123f); }
+// The sine a GPU running xor.wgsl as it stands would use: hardware v_sin_f32 (argument in revolutions) behind a multiply by 1 / 2 pi and
+// v_fract -- how the AMD compilers lower sin().  For the hash's arguments (up to ~8e5, where 1 / 2 pi of an ulp is ~1e-2 revolutions) it
+// returns a few correct bits, and the hash multiplies what is left by 43758: DEV = true renders a DIFFERENT noise field of the same
+// statistics.  A tolerance mode (VK_RENDER_DEVICE_SINE) for the procedural march only; the volume generator always takes the specified sine.
+__device__ __forceinline__ float sin_device(float h) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(h * 0.15915494309189535f)); }
+template <bool DEV>
+__device__ __forceinline__ float xor_hash(float h) { return xor_fract((DEV ? sin_device(h) : sin_spec(h)) * 43758.5453123f); }
+template <bool DEV>
 __device__ __forceinline__ float xor_noise(float x0, float x1, float x2) {
     const float p0 = floorf(x0), p1 = floorf(x1), p2 = floorf(x2);
     float f0 = xor_fract(x0), f1 = xor_fract(x1), f2 = xor_fract(x2);
     f0 = f0 * f0 * (3.0f - 2.0f * f0); f1 = f1 * f1 * (3.0f - 2.0f * f1); f2 = f2 * f2 * (3.0f - 2.0f * f2);
     const float n = p0 + p1 * 157.0f + 113.0f * p2;
-    return xor_mix(xor_mix(xor_mix(xor_hash(n + 0.0f), xor_hash(n + 1.0f), f0), xor_mix(xor_hash(n + 157.0f), xor_hash(n + 158.0f), f0), f1),
-                   xor_mix(xor_mix(xor_hash(n + 113.0f), xor_hash(n + 114.0f), f0), xor_mix(xor_hash(n + 270.0f), xor_hash(n + 271.0f), f0), f1),
+    return xor_mix(xor_mix(xor_mix(xor_hash<DEV>(n + 0.0f), xor_hash<DEV>(n + 1.0f), f0), xor_mix(xor_hash<DEV>(n + 157.0f), xor_hash<DEV>(n + 158.0f), f0), f1),
+                   xor_mix(xor_mix(xor_hash<DEV>(n + 113.0f), xor_hash<DEV>(n + 114.0f), f0), xor_mix(xor_hash<DEV>(n + 270.0f), xor_hash<DEV>(n + 271.0f), f0), f1),
                    f2);
 }
+template <bool DEV>
 __device__ __forceinline__ float xor_fbm(float p0, float p1, float p2) {
-    float f = 0.5000f * xor_noise(p0, p1, p2);
+    float f = 0.5000f * xor_noise<DEV>(p0, p1, p2);
     p0 = p0 * 2.01f; p1 = p1 * 2.01f; p2 = p2 * 2.01f;
-    f = f + 0.2500f * xor_noise(p0, p1, p2);
+    f = f + 0.2500f * xor_noise<DEV>(p0, p1, p2);
     p0 = p0 * 2.02f; p1 = p1 * 2.02f; p2 = p2 * 2.02f;
-    f = f + 0.1250f * xor_noise(p0, p1, p2);
+    f = f + 0.1250f * xor_noise<DEV>(p0, p1, p2);
     return f;
 }
+template <bool DEV = false>
 __device__ __forceinline__ void xor_noise_volume(float c0, float c1, float c2, float off1, float &val, float &alpha) {
-    val = xor_fbm((c0 + 1.0f) * 32.0f, (c1 + off1) * 32.0f, (c2 + 21.0f) * 32.0f);
+    val = xor_fbm<DEV>((c0 + 1.0f) * 32.0f, (c1 + off1) * 32.0f, (c2 + 21.0f) * 32.0f);
     const float len = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
     alpha = val * smoothstepf(0.5f, 0.25f, len);
 }
