@@ -176,6 +176,9 @@ int vk_backbuffer_clear(vk_ctx *ctx);
  * waves of frame i + 1 fill the SIMDs that the tail of frame i leaves idle.  k = 1 (the default) is one slot on the
  * context's stream: the behaviour of ABI 4.  Every frame is bitwise the frame the same calls produce with k = 1.
  *
+ * Of a ring of three or four, k - 1 frames execute at once and one waits, recorded, in its queue (its stream waits on the GPU for
+ * the frame k - 1 before it): the next frame starts the moment one ends, without the host in between.
+ *
  * vk_ctx_frames_in_flight: 1 <= k <= VK_MAX_FRAMES_IN_FLIGHT; drains the context, sizes the ring (new slots take the
  *   backbuffer's current shape, cleared) and forgets earlier frame ids.  Refused while a frame is open, and for k > 1 on a
  *   context that runs on a caller's stream (vk_ctx_set_stream).

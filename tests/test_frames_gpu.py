@@ -219,6 +219,17 @@ def test_run_headless_in_flight(V):
         finally:
             ctx.close()
     assert (shots[1][0].view(np.uint8) == shots[3][0].view(np.uint8)).all() and shots[1][1] == shots[3][1]
+    # the same loop with the present pass in the raycast pass's epilogue (Context.fuse_present): context.render records nothing, the
+    # captured frame is the two-pass one to within one 8-bit step on the f32-off-centre columns / rows
+    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 160 / 90)
+    ctx, _ = V.run_headless(Bonsai, frames=5, camera=cam, width=160, height=90, backbuffer=(160, 90), in_flight=4, fuse_present=True)
+    try:
+        fused = np.frombuffer(ctx.capture_frame()[0], np.uint8).astype(np.int32)
+        assert (ctx.read_backbuffer().view(np.uint8) == shots[1][0].view(np.uint8)).all()
+    finally:
+        ctx.close()
+    d = np.abs(fused - np.frombuffer(shots[1][1], np.uint8).astype(np.int32))
+    assert d.max() <= 1 and (d == 0).mean() > 0.99
 
 
 # ---- present fused into the raycast pass's epilogue (VK_RENDER_PRESENT*) ------------------------------------------------------

@@ -40,11 +40,14 @@ def stream_of_frames(ctx, pipe, cams, frames_api):
     return best, host
 
 
-out = {"lib": os.environ.get("VK_LIB", "product"), "frames": n, "present": "fused" if fused else present}
+out = {"lib": os.environ.get("VK_LIB", "product"), "params": os.environ.get("VK_PARAMS", ""), "frames": n, "present": "fused" if fused else present}
 for name, (w, h), mk, mode, dt, cam0 in (
         ("c2", (1920, 1080), lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
         ("xor720p", (1280, 720), lambda c: V.VolumeTexture.generate_xor(c, (256,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))):
     ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
+    for kv in os.environ.get("VK_PARAMS", "").split(","):  # library knobs: VK_PARAMS=name=value,...
+        if "=" in kv:
+            ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     mk(ctx)
     z, p, y, t = cam0
     cams = [V.Camera(z, p, y + 6.28318 * j / 1024, t, w / h).get_proj_view_matrix() for j in range(128)]

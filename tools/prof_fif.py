@@ -12,6 +12,9 @@ if which == "c2":
 else:
     w, h, mode, dt, cam0 = 1280, 720, V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0))
 ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
+for kv in os.environ.get("VK_PARAMS", "").split(","):
+    if "=" in kv:
+        ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
 if which == "c2":
     V.VolumeTexture.generate_standin(ctx, (256,) * 3)
 else:

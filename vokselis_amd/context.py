@@ -121,6 +121,10 @@ class Context:
         self._timeline = time.perf_counter()
         self._first_frame = True
         self.in_flight = 1
+        # fuse_present: when the window has the backbuffer's size, RaycastPipeline.record presents from the pass's own epilogue
+        # (VK_RENDER_PRESENT) and the render() that follows records nothing -- demo.render + context.render (src/lib.rs:178-182) in one launch
+        self.fuse_present = False
+        self._pass_presented = False
 
     # -- lifetime
     def close(self):
@@ -261,6 +265,9 @@ class Context:
     def render(self):
         """Context::render (src/context.rs:251-297): the present pass -- backbuffer -> ACES + sRGB ->
         Rgba8 at the window size.  (No surface to present to on a compute node.)"""
+        if self._pass_presented:  # the raycast pass has written the presented image itself (fuse_present)
+            self._pass_presented = False
+            return
         N.check(self._h, N.lib().vk_present(self._h, self.width, self.height, 0))
 
     def capture_frame(self):
@@ -393,7 +400,11 @@ class RaycastPipeline:
     def record(self, ctx: Context, tile=None):
         bb = ctx.render_backbuffer
         tx, ty, tw, th = (0, 0, bb.width, bb.height) if tile is None else tile
-        N.check(ctx.handle, N.lib().vk_render(ctx.handle, self.mode, tx, ty, tw, th, self.dt_scale, self.flags))
+        flags = self.flags
+        if ctx.fuse_present and (ctx.width, ctx.height) == (bb.width, bb.height) and not (flags & N.RENDER_COUNT):
+            flags |= N.RENDER_PRESENT
+            ctx._pass_presented = True
+        N.check(ctx.handle, N.lib().vk_render(ctx.handle, self.mode, tx, ty, tw, th, self.dt_scale, flags))
 
     def record_partition(self, ctx: Context, tile_size: int, rank: int, nranks: int, compact_ptr: int):
         """March this rank's tiles of the current camera's frame into a compact buffer (several frames: render_batch)."""
@@ -444,14 +455,17 @@ class Demo:
 
 
 def run_headless(demo_cls, frames: int = 1, camera: Camera | None = None, width: int = 1280, height: int = 720,
-                 backbuffer: tuple | None = None, out_format: int = N.OUT_RGBA16F, device: int = 0, in_flight: int = 1, on_frame=None):
+                 backbuffer: tuple | None = None, out_format: int = N.OUT_RGBA16F, device: int = 0, in_flight: int = 1, on_frame=None,
+                 fuse_present: bool = False):
     """`run::<D>` (src/lib.rs:45-208) without the window: N frames of
     Context.update -> Demo.update -> Demo.render, then returns (ctx, demo).
     in_flight > 1: the loop runs up to that many frames ahead of the GPU, as the reference's queue does (src/lib.rs:178-194), every
-    frame on a surface of its own; on_frame(ctx, frame_id), if given, is called after each frame has been submitted."""
+    frame on a surface of its own; on_frame(ctx, frame_id), if given, is called after each frame has been submitted.
+    fuse_present: the present pass rides in the raycast pass's epilogue when the window has the backbuffer's size (Context.fuse_present)."""
     ctx = Context(width, height, camera, device=device, backbuffer=backbuffer, out_format=out_format)
     if in_flight > 1:
         ctx.frames_in_flight(in_flight)
+    ctx.fuse_present = bool(fuse_present)
     fc = FrameCounter()
     demo = demo_cls.init(ctx)
     for _ in range(frames):

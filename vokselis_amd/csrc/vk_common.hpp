@@ -118,7 +118,12 @@ struct LaunchDesc {
     uint32_t *present_rgba8;       // nullptr: no fused present
     uint32_t *present_bgra8;       // optional surface copy
     uint32_t present_only;         // != 0: the HDR pixel itself is not stored
+    // LF_ORDER_INLINE: the tile order rides in the kernel arguments (single-frame launches of up to kOrderInline tiles): no table upload
+    // in the frame's stream.  Last member: launches that do not use it never touch these bytes.
+    uint16_t order_inline[1024];
 };
+constexpr uint32_t kOrderInline = 1024;
+static_assert(sizeof(LaunchDesc) <= 2560, "LaunchDesc + VolumeDesc + StagedDesc travel as kernel arguments (4 KiB)");
 
 // LaunchDesc::flags.  Policy and instrumentation switches of one launch, set by the host (vk_render.hip) and read by the kernels.
 enum LaunchFlag : uint32_t {
@@ -129,6 +134,7 @@ enum LaunchFlag : uint32_t {
     LF_WAVE_PRIORITY = 16u,       // s_setprio by the length of the wave's longest ray (set_wave_priority)
     LF_FRAME_RUNS = 32u,          // batched launches: every XCD marches a run of consecutive frames of a tile position
     LF_PROBE_AHEAD = 128u,        // skip kernels, fast path: the next position's distance byte is requested under this trip's sample (vk_march.hpp: AHEAD)
+    LF_ORDER_INLINE = 256u,       // map_pixel reads the tile order from LaunchDesc::order_inline (kernel arguments) instead of the device table
     LF_TRIP_LOG = 64u,            // COUNT builds: `trace` holds per-trip logs of trip_log_cap entries per wave (docs/archive/tools/repack_census.py)
 };
 
@@ -222,7 +228,7 @@ __device__ __forceinline__ PixelMap map_pixel(const LaunchDesc &L, const FrameVi
     uint32_t slot = lb / per_tile, sub = lb - slot * per_tile;
     uint32_t pos = deal_pos(L.rank, slot, L.nranks, L.root_skip);  // position in the heaviest-first order
     const uint32_t n_tiles = L.tiles_x * L.tiles_y;
-    uint32_t tile = pos < fv.n_tiles_launch ? fv.order[pos] : n_tiles;
+    uint32_t tile = pos < fv.n_tiles_launch ? ((L.flags & LF_ORDER_INLINE) ? (uint32_t)L.order_inline[pos] : fv.order[pos]) : n_tiles;
     const TilePixel tp = tile_pixel(L.ts, L.tiles_x, tile, sub, lane);  // (vk_hostmath.hpp)
     const uint32_t lx = tp.lx, ly = tp.ly, rx = tp.rx, ry = tp.ry;
     m.x = L.ox + (int32_t)rx;

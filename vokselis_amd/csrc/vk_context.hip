@@ -301,6 +301,17 @@ int vk_frame_begin(vk_ctx *ctx, uint64_t *frame_id) {
     s.id = ++ctx->fif_last_id;
     s.ended = false;
     ctx->fif_open = true;
+    // One frame of a ring of three or four is always RECORDED AND WAITING in its queue while the others execute: this frame's stream waits (on
+    // the GPU) for the end of the frame k - 1 before it.  Single-frame launches dealt to the machine all together share it evenly, end together
+    // and leave it to a lone frame while the host records the next ones (C2, k = 3, no limit: three kernels ran 48 % of the time, a lone one
+    // 31 %, 0.089 ms per frame); with one frame held back the next starts the moment a frame ends, with no host latency in between
+    // (0.080 at k = 3, 0.076 at k = 4; the xor frame 0.055 / 0.050; profiles/r06_frames_in_flight.txt).  fif_concurrent overrides k - 1.
+    const uint32_t conc = ctx->fif_concurrent ? ctx->fif_concurrent : (ctx->fif_k >= 3u ? ctx->fif_k - 1u : ctx->fif_k);
+    if (ctx->fif_k > conc && s.id > conc) {
+        const uint64_t before = s.id - conc;
+        for (uint32_t i = 0; i < ctx->fif_k; i++)
+            if (ctx->fif[i].id == before && ctx->fif[i].ended && i != slot) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->fif[i].done, 0));
+    }
     if (frame_id) *frame_id = s.id;
     return VK_OK;
 }
@@ -435,6 +446,8 @@ int vk_debug_set_param(vk_ctx *ctx, const char *name, double value) {
     else if (n == "stage_grow_every") ctx->stage_grow_every = (uint32_t)value;   // slab search growth period (next render)
     else if (n == "stage_row_pad") ctx->stage_row_pad = (uint32_t)value;          // odd row pitch of the staged window (next render)
     else if (n == "wave_prio") ctx->wave_prio = (uint32_t)value;
+    else if (n == "fif_concurrent") ctx->fif_concurrent = (uint32_t)value;  // frames in flight: how many of the ring's frames may execute at once (0: all)
+    else if (n == "order_never_inline") ctx->order_never_inline = (uint32_t)value;  // A/B: the tile order through the device table for every launch
     else if (n == "walk_cap") ctx->walk_cap = (uint32_t)value;
     else if (n == "walk_cap_all") ctx->walk_cap_all = (uint32_t)value;
     else if (n == "render_tile") ctx->render_tile = ((uint32_t)value & ~7u);

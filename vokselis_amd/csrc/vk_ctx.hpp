@@ -63,6 +63,7 @@ struct vk_ctx {
     // heaviest-first tile order (launch-order heuristic; see tile_order_update)
     std::vector<uint32_t> order, order_pos;
     uint32_t order_active = 0;  // leading positions of `order` whose tiles can contain non-clear pixels
+    bool order_on_device = false;  // the current slot of the device ring holds `order` / `order_pos` (single-frame launches of few tiles carry the order in their kernel arguments)
     std::vector<unsigned char> order_key;
     unsigned long long *trace = nullptr;
     size_t trace_blocks = 0;
@@ -114,6 +115,7 @@ struct vk_ctx {
     uint32_t probe_ahead = 2;    // skip kernels: request the next position's distance byte under the sample (0 never, 1 always, 2 single-frame launches)
     uint32_t order_rays = 3;     // estimate rays per tile edge of the heaviest-first order (single-frame launches)
     uint32_t order_rays_batch = 1;  // ... of launches spanning >= 4 frames
+    uint32_t order_never_inline = 0;  // debug / A-B: single-frame launches read the tile order from the device table as before round 6
     uint32_t wave_prio = 1;      // issue priority by ray length (set_wave_priority); 0 for A/B measurements
     uint32_t naive_lds_pad = 0;  // debug: extra dynamic LDS per workgroup of the cell kernels (caps the waves per SIMD)
     uint32_t root_skip = 0;  // dealing: rank 0 sits out every root_skip-th round (vk_partition_root_skip)
@@ -137,6 +139,7 @@ struct vk_ctx {
         bool ended = false;            // ... and whether vk_frame_end has recorded `done` for it
     } fif[VK_MAX_FRAMES_IN_FLIGHT];
     uint32_t fif_k = 1, fif_cur = 0;
+    uint32_t fif_concurrent = 0;  // frames of the ring that may EXECUTE at once (vk_frame_begin); 0: k - 1 for k >= 3 -- one frame always waits, recorded, in its queue
     uint64_t fif_seq = 0;       // frames begun since the ring was sized: frame number n takes slot n % fif_k
     uint64_t fif_last_id = 0;   // ids handed out so far (never reused by a context)
     bool fif_open = false;      // between vk_frame_begin and vk_frame_end
@@ -181,7 +184,8 @@ void comm_release(vk_ctx *ctx);  // vk_comm.hip
 void cull_rect_cam(const vk_ctx *ctx, const float *cam, int mode, int32_t r[4]);
 void compute_tile_order_raw(const vk_ctx *ctx, const float *cam, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts,
                             uint32_t *order, uint32_t *order_pos, uint32_t &order_active, int G);
-int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts);
+int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts, bool need_device);
+int order_ensure_device(vk_ctx *ctx);
 int order_wait(vk_ctx *ctx);
 
 // vk_post.hip

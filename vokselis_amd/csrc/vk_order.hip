@@ -40,15 +40,31 @@ static void order_note_use(vk_ctx *ctx) {
     ctx->ring_use_frame[ctx->ring_slot] = ctx->fif_open ? ctx->fif[ctx->fif_cur].id : 0;
 }
 
-int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts) {
+// The order of the context's camera for a region: computed on the host when the key (camera, region, frame and volume shape) changes, and
+// -- need_device -- uploaded to the next slot of the device ring.  A whole-pixel single-frame launch of up to kOrderInline tiles carries the
+// order in its kernel arguments instead (LaunchDesc::order_inline) and asks for no upload: the copy was a blit kernel of ~10 us in the
+// frame's own stream, on a frame of 140.
+int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw, uint32_t rh, uint32_t ts, bool need_device) {
     const uint32_t tx = (rw + ts - 1) / ts, ty = (rh + ts - 1) / ts;
     const size_t n = (size_t)tx * ty;
     std::vector<unsigned char> key(144 + 40);
     std::memcpy(key.data(), ctx->camera, 144);
     const uint32_t kk[10] = {(uint32_t)mode, (uint32_t)ox, (uint32_t)oy, rw, rh, ts, ctx->width, ctx->height, ctx->nx ^ (ctx->ny << 10) ^ (ctx->nz << 20), 0};
     std::memcpy(key.data() + 144, kk, 40);
-    if (key == ctx->order_key && ctx->order.size() == n) { order_note_use(ctx); return VK_OK; }
-    compute_tile_order(ctx, ctx->camera, mode, ox, oy, rw, rh, ts, ctx->order, ctx->order_pos, ctx->order_active);
+    if (!(key == ctx->order_key && ctx->order.size() == n)) {
+        compute_tile_order(ctx, ctx->camera, mode, ox, oy, rw, rh, ts, ctx->order, ctx->order_pos, ctx->order_active);
+        ctx->order_key = key;
+        ctx->order_on_device = false;
+    }
+    if (!need_device) return VK_OK;
+    return order_ensure_device(ctx);
+}
+
+// The host's current order on the device (a no-op when it is there already).
+int order_ensure_device(vk_ctx *ctx) {
+    if (ctx->order_on_device) { order_note_use(ctx); return VK_OK; }
+    const size_t n = ctx->order.size();
+    if (n == 0) return fail(ctx, VK_ERR_INVALID, "no tile order yet");
     const uint32_t n_active = ctx->order_active;
     constexpr int kOrderRing = 16;
     if (ctx->d_order_cap < n) {
@@ -101,7 +117,7 @@ int tile_order_update(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t rw
     ctx->ring_slot = slot;
     ctx->d_order = ds;
     ctx->d_order_pos = ds + cap;
-    ctx->order_key = key;
+    ctx->order_on_device = true;
     order_note_use(ctx);
     return VK_OK;
 }
@@ -182,7 +198,7 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
     if (tile_size == 0 || (tile_size & 7u) || nranks == 0) return fail(ctx, VK_ERR_INVALID, "bad tile size / nranks");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the same geometry key as the render calls use (PROCEDURAL marches the compute twin's rays)
-    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size);
+    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size, false);
     if (orc) return orc;
     if (n_active_tiles) *n_active_tiles = ctx->order_active;
     if (n_active_slots) *n_active_slots = deal_rounds(ctx->order_active, nranks, nranks > 1 ? ctx->root_skip : 0u);
@@ -192,13 +208,16 @@ int vk_partition_active(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t nran
 int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n) {
     // experiment hook: replace the current (already computed) order table; stays until the key changes
     if (!ctx || !order) return VK_ERR_INVALID;
-    if (n != ctx->order.size() || !ctx->d_order) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: no order of that size");
+    if (n != ctx->order.size()) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: no order of that size");
+    for (uint32_t q = 0; q < n; q++) if (order[q] >= n) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: not a permutation of the tiles");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipDeviceSynchronize());
     for (uint32_t q = 0; q < n; q++) { ctx->order[q] = order[q]; ctx->order_pos[order[q]] = q; }
-    HIP_TRY(ctx, hipMemcpy(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (ctx->order_on_device) {
+        HIP_TRY(ctx, hipMemcpy(ctx->d_order, ctx->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_order_pos, ctx->order_pos.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return VK_OK;
 }
 
@@ -209,7 +228,7 @@ int vk_partition_order(vk_ctx *ctx, int mode, uint32_t tile_size, uint32_t *orde
         return fail(ctx, VK_ERR_INVALID, "vk_partition_order: needs camera and backbuffer (and a volume, except PROCEDURAL)");
     if (tile_size == 0 || (tile_size & 7u)) return fail(ctx, VK_ERR_INVALID, "tile size must be a multiple of 8");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size);
+    int orc = tile_order_update(ctx, mode == VK_MODE_PROCEDURAL ? VK_MODE_COMPUTE_NEAREST : mode, 0, 0, ctx->width, ctx->height, tile_size, false);
     if (orc) return orc;
     if (n_tiles != ctx->order.size()) return fail(ctx, VK_ERR_INVALID, "vk_partition_order: n_tiles does not match the partition");
     std::memcpy(order_out, ctx->order.data(), n_tiles * sizeof(uint32_t));

@@ -24,11 +24,12 @@ static int untile_common(vk_ctx *ctx, const void *gathered, uint32_t tile_size, 
     // The un-tile follows the order the partitions were marched with: the tables of the LAST partition call,
     // not those of a camera uploaded since.  Only a context that has never partitioned this frame shape derives them here.
     const size_t n_tiles = (size_t)tiles_x * ((ctx->height + tile_size - 1) / tile_size);
-    if (!ctx->d_order_pos || ctx->order.size() != n_tiles) {
+    if (ctx->order.size() != n_tiles) {
         const int m = ctx->format == VK_FMT_RGBA16F_PAIR || ctx->format < 0 ? VK_MODE_COMPUTE_NEAREST : VK_MODE_NAIVE_TRILINEAR;
-        int orc = tile_order_update(ctx, m, 0, 0, ctx->width, ctx->height, tile_size);
+        int orc = tile_order_update(ctx, m, 0, 0, ctx->width, ctx->height, tile_size, true);
         if (orc) return orc;
     }
+    { int orc = order_ensure_device(ctx); if (orc) return orc; }  // (the tables as the partition left them)
     int owc = order_wait(ctx);
     if (owc) return owc;
     const uint32_t *d_pos = ctx->d_order_pos;

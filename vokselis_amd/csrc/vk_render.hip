@@ -150,12 +150,20 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
         L.cull_x0 = cr[0]; L.cull_y0 = cr[1]; L.cull_x1 = cr[2]; L.cull_y1 = cr[3];
     }
     L.rank = rank; L.nranks = nranks;
+    // whole-pixel launches of few tiles (C2 at 64-pixel tiles: 510) carry the order in their arguments; partitions and large tile counts
+    // read the device table (the partition's un-tile needs it there anyway)
+    const bool order_inline = !compact_out && (uint64_t)L.tiles_x * L.tiles_y <= kOrderInline && !ctx->order_never_inline;
     {
-        int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts);
+        int orc = tile_order_update(ctx, geo_mode, ox, oy, rw, rh, ts, !order_inline);
         if (orc) return orc;
-        orc = order_wait(ctx);
-        if (orc) return orc;
-        L.tile_order = ctx->d_order;
+        if (order_inline) {
+            for (size_t q = 0; q < ctx->order.size(); q++) L.order_inline[q] = (uint16_t)ctx->order[q];
+            L.tile_order = nullptr;
+        } else {
+            orc = order_wait(ctx);
+            if (orc) return orc;
+            L.tile_order = ctx->d_order;
+        }
     }
     // a partition (compact output) covers only the active tiles; a plain render covers the whole region
     const uint64_t tiles = compact_out ? (uint64_t)ctx->order_active : (uint64_t)L.tiles_x * L.tiles_y;
@@ -177,7 +185,7 @@ static int render_common(vk_ctx *ctx, int mode, int32_t ox, int32_t oy, uint32_t
     L.trace = nullptr;
     L.frames = nullptr;
     L.n_frames = 1;
-    L.flags = launch_flags(ctx, flags, false);
+    L.flags = launch_flags(ctx, flags, false) | (order_inline ? (uint32_t)LF_ORDER_INLINE : 0u);
     L.walk_cap = ctx->walk_cap ? (float)ctx->walk_cap : HUGE_VALF;
     L.walk_cap_all = ctx->walk_cap_all ? (float)ctx->walk_cap_all : HUGE_VALF;
     L.pair_walk_min = ctx->pair_walk_min;

@@ -4,7 +4,7 @@
 //          [--f32] [--dump-rgba file] [--dump-steps file]   parity surface (rgba32f) + per-pixel trip counts, raw
 //          [--gpus N] [--batch B] [--peer-direct]            the frame's tiles over N GPUs of this node (vk_group_*); --peer-direct: the GPUs
 //                                                            store into GPU 0's frames themselves instead of gather + un-tile
-//          [--in-flight K] [--orbit]                          K frames in flight (vk_ctx_frames_in_flight); --orbit: the camera turns by 2 pi / 1024 every frame
+//          [--in-flight K] [--orbit] [--fuse-present]                        K frames in flight (vk_ctx_frames_in_flight); --orbit: the camera turns by 2 pi / 1024 every frame
 //          [--camera-blobs orbits.txt out.bin]              no GPU: one 144-byte CameraUniform per "zoom pitch yaw tx ty tz aspect" line
 #include <cstdio>
 #include <algorithm>
@@ -107,7 +107,7 @@ static int dump_camera_blobs(const std::string &in, const std::string &out) {
 int main(int argc, char **argv) {
     uint32_t frames = 100, w = 1280, h = 720, batch = 8, in_flight = 1;
     int gpus = 0;
-    bool f32 = false, peer_direct = false;
+    bool f32 = false, peer_direct = false, fuse_present = false;
     std::string ppm, dump_rgba, dump_steps;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -124,6 +124,7 @@ int main(int argc, char **argv) {
         else if (a == "--peer-direct") peer_direct = true;
         else if (a == "--in-flight") in_flight = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--orbit") g_orbit = true;
+        else if (a == "--fuse-present") fuse_present = true;
         else if (a == "--batch") batch = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--camera-blobs") { std::string in = next(); return dump_camera_blobs(in, next()); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -135,6 +136,7 @@ int main(int argc, char **argv) {
         HdrBackBuffer bb; bb.width = w; bb.height = h;
         if (f32) bb.format = VK_OUT_RGBA32F;
         Context ctx(w, h, &camera, 0, bb);
+        ctx.fuse_present = fuse_present;  // (the present pass in the raycast pass's epilogue: VK_RENDER_PRESENT)
         std::printf("%s\n", ctx.get_info().c_str());
         double ms = 0;
         auto demo = run_headless<Bonsai>(ctx, frames, &ms, in_flight);

@@ -199,6 +199,10 @@ class Context {
     Uniform global_uniform;
     HdrBackBuffer render_backbuffer;
     uint32_t width, height;
+    // fuse_present: when the window has the backbuffer's size, RaycastPipeline::record presents from the pass's own epilogue
+    // (VK_RENDER_PRESENT) and the render() that follows records nothing: demo.render + context.render (src/lib.rs:178-182) in one launch
+    bool fuse_present = false;
+    bool pass_presented = false;
 
     Context(uint32_t w, uint32_t h, const Camera *cam = nullptr, int device = 0, HdrBackBuffer bb = HdrBackBuffer())
         : camera(cam ? *cam : Camera(1.f, 0.5f, 1.f, {0.f, 0.f, 0.f}, (float)w / (float)h)), render_backbuffer(bb), width(w), height(h) {
@@ -247,7 +251,14 @@ class Context {
     }
     // Context::render (context.rs:251-297): the present pass -- backbuffer -> ACES + sRGB -> Rgba8 at the
     // window size.  There is no surface to present to on a compute node.
-    void render() { check(ctx_, vk_present(ctx_, width, height, 0)); }
+    void render() {
+        if (pass_presented) { pass_presented = false; return; }  // (the raycast pass has written the presented image itself)
+        check(ctx_, vk_present(ctx_, width, height, 0));
+    }
+    uint32_t pass_flags(uint32_t flags) {  // what RaycastPipeline adds to a pass's flags under fuse_present
+        if (fuse_present && width == render_backbuffer.width && height == render_backbuffer.height && !(flags & VK_RENDER_COUNT)) { pass_presented = true; return flags | VK_RENDER_PRESENT; }
+        return flags;
+    }
     // capture_frame (context.rs:299-302, screenshot.rs:37-77): the presented Rgba8 frame, rows padded to 256 B
     std::pair<std::vector<uint8_t>, ImageDimentions> capture_frame() {
         ImageDimentions dims(width, height, 256);
@@ -324,10 +335,10 @@ struct RaycastPipeline {
     uint32_t flags = 0;
     void record(Context &ctx) const {
         const HdrBackBuffer &bb = ctx.render_backbuffer;
-        check(ctx.handle(), vk_render(ctx.handle(), mode, 0, 0, bb.width, bb.height, dt_scale, flags));
+        check(ctx.handle(), vk_render(ctx.handle(), mode, 0, 0, bb.width, bb.height, dt_scale, ctx.pass_flags(flags)));
     }
     void record_tile(Context &ctx, int32_t x, int32_t y, uint32_t w, uint32_t h) const {
-        check(ctx.handle(), vk_render(ctx.handle(), mode, x, y, w, h, dt_scale, flags));
+        check(ctx.handle(), vk_render(ctx.handle(), mode, x, y, w, h, dt_scale, ctx.pass_flags(flags)));
     }
 };
 

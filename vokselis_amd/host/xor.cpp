@@ -1,7 +1,7 @@
 // xor.cpp -- headless counterpart of `cargo run --example xor` (examples/xor/main.rs): the procedural
 // volume (shaders/xor.wgsl) marched by the compute raycast (shaders/raycast_compute.wgsl), either as
 // one `single` dispatch or as the reference's loop of 256-pixel `tile` dispatches with offsets.
-//   xor [--frames N] [--size WxH] [--mode single|tile|procedural] [--volume N] [--time T] [--ppm out.ppm] [--in-flight K]
+//   xor [--frames N] [--size WxH] [--mode single|tile|procedural] [--volume N] [--time T] [--ppm out.ppm] [--in-flight K] [--fuse-present]
 // `procedural` marches shaders/xor.wgsl's density function itself, no volume; --time pins un.time.
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +49,7 @@ struct Xor : Demo {
 
 int main(int argc, char **argv) {
     uint32_t frames = 100, w = 1280, h = 720, in_flight = 1;
+    bool fuse_present = false;
     std::string ppm;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -59,6 +60,7 @@ int main(int argc, char **argv) {
         else if (a == "--time") { g_time = (float)std::atof(next()); g_pin_time = true; }
         else if (a == "--volume") g_vol = (uint32_t)std::atoi(next());
         else if (a == "--ppm") ppm = next();
+        else if (a == "--fuse-present") fuse_present = true;
         else if (a == "--in-flight") in_flight = (uint32_t)std::atoi(next());  // frames in flight (vk_ctx_frames_in_flight)
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -66,6 +68,7 @@ int main(int argc, char **argv) {
         Camera camera(3.f, -0.5f, 1.f, {0.f, 0.f, 0.f}, (float)w / (float)h);  // examples/xor/main.rs:273-279
         HdrBackBuffer bb; bb.width = w; bb.height = h;
         Context ctx(w, h, &camera, 0, bb);
+        ctx.fuse_present = fuse_present;  // (the present pass in the raycast pass's epilogue: VK_RENDER_PRESENT)
         std::printf("%s\n", ctx.get_info().c_str());
         double ms = 0;
         auto demo = run_headless<Xor>(ctx, frames, &ms, in_flight ? in_flight : 1);
