@@ -50,7 +50,7 @@ def tile_of(cfg) -> int:
     return 32 if cfg["fmt"] != "u8" else 64
 
 
-PROF = "r05"  # prefix of the PMC-derived files under profiles/ this line quotes (tools/prof.sh, tools/pmc_traffic.py, tools/utilisation.py)
+PROF = "r06"  # prefix of the PMC-derived files under profiles/ this line quotes (tools/prof.sh, tools/pmc_traffic.py, tools/utilisation.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock (same guide); an f32 full-rate wave64 instruction holds a SIMD for 2 cycles,

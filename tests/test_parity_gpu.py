@@ -1,4 +1,5 @@
-"""GPU suite: the HIP path, called through the C-ABI, against the CPU oracle and the golden vectors.
+"""GPU suite: the naive march (raycast_naive.wgsl) -- cell layouts, f16 volumes, the staged 8^3 bricks, BASELINE configs at full size, skipping,
+the tolerance walk -- called through the C-ABI, against the CPU oracle and the golden vectors.
 
 Bars: per-channel |dRGBA| <= 1e-4 on the f32 surface (north star); loop trip counts (S_ref) and
 the count of tap-fetching steps (S_sampled) are integer work and must be *identical*.
@@ -8,65 +9,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from gpu_helpers import TOL, V, _captured_rgb, _holes_volume, _orbit_cameras, _render_with_params, _synced, gpu_render, layouts  # noqa: F401
+
 pytestmark = pytest.mark.gpu
-
-TOL = 1e-4
-
-
-@pytest.fixture(scope="module")
-def V(hip_built):
-    import torch
-
-    if not torch.cuda.is_available():
-        pytest.fail("no GPU: the gpu suite must run on an MI355X box")
-    import vokselis_amd
-
-    return vokselis_amd
-
-
-def gpu_render(V, cam_blob, vol, W, H, *, dt=1.0, layout=None, flags=0, out=None, tile=None, vol2=None, mode=None,
-               want_steps=True):
-    out = V.OUT_RGBA32F if out is None else out
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=out)
-    try:
-        V.VolumeTexture(ctx, vol, vol2, layout=V.LAYOUT_AUTO if layout is None else layout)
-        ctx.set_camera_blob(cam_blob)
-        ctx.reset_step_counts()
-        if not (flags & V.RENDER_NO_SKIP):
-            # exercise the skip path whatever the volume's empty share, probing on every trip so that S_sampled is exactly
-            # the count of steps that can contribute (the adaptive policy has its own test)
-            flags |= V.RENDER_FORCE_SKIP | V.RENDER_PROBE_ALWAYS
-        pipe = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR if mode is None else mode, dt_scale=dt,
-                                 flags=flags | (V.RENDER_COUNT if want_steps else 0))
-        pipe.record(ctx, tile)
-        img = ctx.read_backbuffer()
-        steps = ctx.read_steps() if want_steps else None
-        counts = ctx.step_counts() if want_steps else None
-        if want_steps:
-            # the production (uninstrumented) kernel must reproduce the instrumented frame bit for bit
-            V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
-            V.RaycastPipeline(pipe.mode, dt_scale=dt, flags=flags).record(ctx, tile)
-            again = ctx.read_backbuffer()
-            if tile is None:
-                assert (again.view(np.uint8) == img.view(np.uint8)).all(), "production path differs from the instrumented one"
-        return img, steps, counts
-    finally:
-        ctx.close()
-
-
-def _synced(t):
-    """A tensor torch has just filled on ITS current stream, handed to the library, which writes on a non-blocking stream of
-    its own: without a synchronisation nothing orders the fill before the library's kernels (torch's streams and the
-    context's do not synchronise with the legacy default stream)."""
-    import torch
-
-    torch.cuda.synchronize()
-    return t
-
-
-def layouts(V):
-    return {"P8": V.LAYOUT_PACKED, "P16": V.LAYOUT_PACKED_PAIRS, "LIN": V.LAYOUT_LINEAR, "B9": V.LAYOUT_BRICKED, "Q": V.LAYOUT_QUADS,
-            "S8": V.LAYOUT_STAGED}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -143,18 +88,6 @@ def test_paced_walks_are_exact(V, O):
                         assert counts[1] == first[1][1]  # exactly the steps that can contribute, however the walks were cut
         finally:
             ctx.close()
-
-
-def _holes_volume(n, p_empty, seed=3, block=16):
-    """u8 fog 26..40 (every cell contributes) with 16^3 blocks knocked out to value 10 (exactly transparent) with
-    probability p_empty: the share of skippable cells is close to p_empty."""
-    rng = np.random.default_rng(seed)
-    vol = rng.integers(26, 41, (n, n, n), dtype=np.uint8)
-    nb = n // block
-    holes = rng.random((nb, nb, nb)) < p_empty
-    mask = np.repeat(np.repeat(np.repeat(holes, block, 0), block, 1), block, 2)
-    vol[mask] = 10
-    return vol
 
 
 def test_adaptive_skip_policy_is_exact(V, O):
@@ -250,489 +183,6 @@ def test_tiles_and_offscreen(V, O, cameras, golden_volumes):
         ctx.close()
 
 
-def test_partition_untile_equals_frame(V, O):
-    """Multi-GPU scheme on one GPU: every rank's partition, concatenated, un-tiles to the frame."""
-    from vokselis_amd import dist as D
-
-    vol = O.volume_standin_u8(64)
-    W, H, ts = 200, 136, 32
-    cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H)
-    ref, _, _ = O.render(cam, vol, W, H, dt_scale=0.5)
-    import torch
-
-    for world in (1, 2, 3, 8):
-        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-        try:
-            V.VolumeTexture(ctx, vol)
-            ctx.set_camera_blob(cam)
-            slots = V.partition_slots(W, H, ts, world)
-            gathered = _synced(torch.zeros((world, slots, ts, ts, 4), dtype=torch.float32, device="cuda"))
-            pipe = V.RaycastPipeline(dt_scale=0.5)
-            for r in range(world):
-                pipe.record_partition(ctx, ts, r, world, gathered[r].data_ptr())
-            ctx.sync()
-            order = ctx.partition_order(ts)
-            assert sorted(order.tolist()) == list(range(len(order)))  # a permutation of the tiles
-            n_active, n_slots_active = ctx.partition_active(ts, world)
-            assert 0 < n_active < len(order) and n_slots_active == -(-n_active // world)
-            g_host = gathered.cpu().numpy()
-            g_host[:, n_slots_active:] = np.nan  # slots beyond the active ones are never read
-            host = D.untile_reference(g_host, W, H, ts, order, n_active)
-            assert np.abs(host - ref).max() <= TOL
-            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, world, slots))
-            img = ctx.read_backbuffer()
-            assert (img == host).all()
-            # the same partition with colour-only tiles (VK_WIRE_RGB): three quarters of the bytes, the same frame
-            ctx.set_wire(V.WIRE_RGB)
-            lean = _synced(torch.full((world, slots, ts * ts * 3), np.nan, dtype=torch.float32, device="cuda"))
-            for r in range(world):
-                pipe.record_partition(ctx, ts, r, world, lean[r].data_ptr())
-            V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, lean.data_ptr(), ts, world, slots))
-            img = ctx.read_backbuffer()
-            assert (img.view(np.uint32) == host.view(np.uint32)).all()
-            ctx.set_wire(V.WIRE_RGBA)
-        finally:
-            ctx.close()
-
-
-def test_silhouette_cull_never_drops_a_hit_tile(V, O):
-    """Tiles the cube's projected silhouette (convex hull of its corners, 2 px of margin) cannot reach are never marched
-    nor gathered; the root clears them.  60 seeded cameras -- far, close, grazing, nearly axis-aligned, inside -- at two
-    tile sizes: compact partition + vk_untile must give the frame vk_render writes (which marches every pixel), bitwise."""
-    import torch
-
-    rng = np.random.default_rng(0xC011)
-    vol = O.volume_fog_u8(24, seed=5)
-    W, H = 208, 120
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        V.VolumeTexture(ctx, vol)
-        pipe = V.RaycastPipeline(dt_scale=1.0)
-        fewer = 0
-        for case in range(60):
-            zoom = float(rng.choice([0.3, 0.8, 1.0, 1.6, 3.0, 6.0]))
-            pitch = float(rng.uniform(-1.5, 1.5)) if case % 5 else float(rng.choice([0.0, 1e-3, 1.5]))
-            yaw = float(rng.uniform(0, 6.283)) if case % 7 else float(rng.choice([0.0, 1.5708, 3.1416]))
-            tgt = tuple(float(v) for v in (rng.uniform(0.2, 0.8, 3) if case % 3 else (0.5, 0.5, 0.5)))
-            ctx.set_camera_blob(O.camera_blob(zoom, pitch, yaw, tgt, W / H))
-            pipe.record(ctx)
-            whole = ctx.read_backbuffer()
-            for ts in (16, 32):
-                slots = V.partition_slots(W, H, ts, 1)
-                gathered = _synced(torch.full((1, slots, ts, ts, 4), float("nan"), dtype=torch.float32, device="cuda"))
-                pipe.record_partition(ctx, ts, 0, 1, gathered.data_ptr())
-                n_active, _ = ctx.partition_active(ts, 1)
-                V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, 1, slots))
-                img = ctx.read_backbuffer()
-                assert (img == whole).all(), (case, ts, zoom, pitch, yaw, tgt)
-                # the hull is at least as tight as the bounding rectangle, and tighter somewhere
-                tx, ty = -(-W // ts), -(-H // ts)
-                hit = (whole[..., :3] != 0).any(axis=-1)
-                touched = sum(bool(hit[j * ts:(j + 1) * ts, i * ts:(i + 1) * ts].any()) for j in range(ty) for i in range(tx))
-                assert touched <= n_active <= tx * ty
-                if hit.any():
-                    ys, xs = np.nonzero(hit)
-                    rect = (xs.max() // ts - xs.min() // ts + 1) * (ys.max() // ts - ys.min() // ts + 1)
-                    fewer += n_active < rect
-        assert fewer > 10  # (the rectangle alone would keep all of them)
-    finally:
-        ctx.close()
-
-
-def test_render_batch_equals_single_frames(V, O):
-    """vk_render_batch: B frames with B different cameras in ONE launch (whole frames at N = 1; per-rank compact
-    tiles + vk_untile_batch for N in {1, 2, 3, 8} emulated on this GPU) -- every frame bitwise equal to vk_render's,
-    on the cell layout with skipping (u8), on the staged bricks (f16) and in the compute twin."""
-    import torch
-
-    W, H, ts = 320, 200, 32
-    cams = [V.Camera(1.0 + 0.05 * k, 0.5 - 0.08 * k, 1.0 + 0.35 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(6)]
-    cams.insert(3, cams[2])  # a repeated camera inside the batch
-    cases = [("standin u8 / cells+skip", O.volume_standin_u8(64), None, V.LAYOUT_AUTO, V.MODE_NAIVE_TRILINEAR, V.OUT_RGBA16F, cams),
-             ("fog f16 / staged bricks", O.volume_fog_f16(48), None, V.LAYOUT_STAGED, V.MODE_NAIVE_TRILINEAR, V.OUT_RGBA32F, cams)]
-    for name, vol, vol2, lay, mode, fmt, cc in cases:
-        ctx = V.Context(W, H, backbuffer=(W, H), out_format=fmt)
-        try:
-            V.VolumeTexture(ctx, vol, vol2, layout=lay)
-            pipe = V.RaycastPipeline(mode, dt_scale=0.5)
-            tdt = torch.float16 if fmt == V.OUT_RGBA16F else torch.float32
-            singles = []
-            for c in cc:
-                ctx.set_camera_blob(c)
-                pipe.record(ctx)
-                singles.append(ctx.read_backbuffer().copy())
-            B = len(cc)
-            frames = _synced(torch.zeros((B, H, W, 4), dtype=tdt, device="cuda"))
-            V.render_batch(ctx, pipe, cc, frames.data_ptr(), tile_size=ts)
-            ctx.sync()
-            got = frames.cpu().numpy()
-            for k in range(B):
-                assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), (name, "whole frames", k)
-            for nr, k in ((1, 0), (2, 0), (3, 2), (8, 3), (8, 0), (2, 5)):
-                ctx.set_root_skip(k)
-                cap = V.partition_slots(W, H, ts, nr, k)
-                gathered = None
-                for r in range(nr):
-                    buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=tdt, device="cuda"))
-                    bid, act = V.render_batch(ctx, pipe, cc, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
-                    if gathered is None:
-                        gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=tdt, device="cuda"))
-                    ctx.sync()
-                    gathered[r] = buf[:act]  # what the rank would send: a contiguous prefix
-                frames.zero_()
-                torch.cuda.synchronize()  # torch's copies and fill (its own stream) before the library reads / writes them
-                V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
-                ctx.sync()
-                got = frames.cpu().numpy()
-                for j in range(B):
-                    assert (got[j].view(np.uint8) == singles[j].view(np.uint8)).all(), (name, "ranks", nr, "root_skip", k, j)
-            ctx.set_root_skip(0)
-        finally:
-            ctx.close()
-    # more than eight frames: every XCD takes a run of consecutive frames of a tile position (frame_runs, the default) -- a relabelling of which
-    # block renders which frame, for counts that are and are not multiples of eight, whole frames and a partition's compact tiles
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    try:
-        V.VolumeTexture(ctx, O.volume_standin_u8(64))
-        pipe = V.RaycastPipeline(dt_scale=0.5)
-        many = [V.Camera(1.0, 0.5, 1.0 + 0.11 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(24)]
-        singles = []
-        for c in many:
-            ctx.set_camera_blob(c)
-            pipe.record(ctx)
-            singles.append(ctx.read_backbuffer().copy())
-        for B in (9, 19, 24):
-            for runs in (1, 0):
-                ctx.set_param("frame_runs", runs)
-                # (the partition's tiles also as colour only -- VK_WIRE_RGB: (r, g) plane + b plane per record, alpha restored by the un-tile)
-                wire = V.WIRE_RGB if runs else V.WIRE_RGBA
-                ch = 3 if wire == V.WIRE_RGB else 4
-                ctx.set_wire(wire)
-                assert ctx.wire_pixel_bytes == 2 * ch
-                frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda"))
-                V.render_batch(ctx, pipe, many[:B], frames.data_ptr(), tile_size=ts)
-                ctx.sync()
-                got = frames.cpu().numpy()
-                for k in range(B):
-                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), ("frame runs", runs, B, "whole frames", k)
-                nr = 3
-                cap = V.partition_slots(W, H, ts, nr, 0)
-                gathered = None
-                for r in range(nr):
-                    buf = _synced(torch.full((cap, B, ts * ts * ch), 7.0, dtype=torch.float16, device="cuda"))
-                    bid, act = V.render_batch(ctx, pipe, many[:B], buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
-                    if gathered is None:
-                        gathered = _synced(torch.zeros((nr, act, B, ts * ts * ch), dtype=torch.float16, device="cuda"))
-                    ctx.sync()
-                    gathered[r] = buf[:act]
-                frames.zero_()
-                torch.cuda.synchronize()
-                V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
-                ctx.sync()
-                got = frames.cpu().numpy()
-                for k in range(B):
-                    assert (got[k].view(np.uint8) == singles[k].view(np.uint8)).all(), ("frame runs", runs, B, "ranks", nr, k)
-        ctx.set_param("frame_runs", 1)
-        # a batch dealt in one wire format (the last one above: whole pixels) is not un-tiled in another
-        ctx.set_wire(V.WIRE_RGB)
-        with pytest.raises(V.VokselisError):
-            V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
-        ctx.set_wire(V.WIRE_RGBA)
-    finally:
-        ctx.close()
-    # the compute twin (records layout) and the procedural mode (no volume) through the same batched launch
-    xcams = [V.Camera(3.0 + 0.1 * k, -0.5 + 0.1 * k, 1.0 + 0.4 * k, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix() for k in range(4)]
-    for mode, dt in ((V.MODE_COMPUTE_NEAREST, 1.0), (V.MODE_PROCEDURAL, 3.0)):
-        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-        try:
-            if mode == V.MODE_COMPUTE_NEAREST:
-                V.VolumeTexture.generate_xor(ctx, (64, 64, 64), 0.0)
-            pipe = V.RaycastPipeline(mode, dt_scale=dt)
-            singles = []
-            for c in xcams:
-                ctx.set_camera_blob(c)
-                pipe.record(ctx)
-                singles.append(ctx.read_backbuffer().copy())
-            frames = _synced(torch.zeros((len(xcams), H, W, 4), dtype=torch.float32, device="cuda"))
-            V.render_batch(ctx, pipe, xcams, frames.data_ptr(), tile_size=ts)
-            ctx.sync()
-            got = frames.cpu().numpy()
-            for j in range(len(xcams)):
-                assert (got[j].view(np.uint32) == singles[j].view(np.uint32)).all(), (mode, j)
-        finally:
-            ctx.close()
-    # error behaviour: counters are per frame, capacity is checked
-    ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
-    try:
-        V.VolumeTexture(ctx, O.volume_fog_u8(16))
-        buf = _synced(torch.zeros((4, 64, 64, 4), device="cuda"))
-        cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.0)
-        with pytest.raises(V.VokselisError):
-            V.render_batch(ctx, V.RaycastPipeline(flags=V.RENDER_COUNT), [cam], buf.data_ptr())
-        # whole-frame addressing with nranks > 1 is a rank's share written at its place in frames that live elsewhere (peer-direct tiles,
-        # vk_group_peer_direct): two "ranks" of one context fill one buffer, rank 0 clearing the tiles the silhouette cannot reach
-        V.render_batch(ctx, V.RaycastPipeline(), [cam] * 4, buf.data_ptr())
-        ctx.sync()
-        whole = buf.cpu().numpy().copy()
-        buf.fill_(-3.0); torch.cuda.synchronize()
-        for rk in (1, 0):
-            V.render_batch(ctx, V.RaycastPipeline(), [cam] * 4, buf.data_ptr(), tile_size=16, rank=rk, nranks=2)
-        ctx.sync()
-        assert (buf.cpu().numpy().view(np.uint32) == whole.view(np.uint32)).all()
-        with pytest.raises(V.VokselisError):
-            V.render_batch(ctx, V.RaycastPipeline(), [cam], buf.data_ptr(), compact=True, slot_capacity=0)
-    finally:
-        ctx.close()
-
-
-def _orbit_cameras(V, n, aspect):
-    return [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), aspect).get_proj_view_matrix() for k in range(n)]
-
-
-def test_c2_full_size_batch_and_eight_way_partition(V, O):
-    """The headline configuration at its own size (256^3 stand-in, 1920x1080, dt 0.5, rgba16f): frames of a batched launch
-    and of an 8-rank partition with the weighted deal (emulated on this GPU, gathered by copies) are bitwise equal to
-    vk_render's frames, whose trip counts are the oracle's."""
-    import torch
-
-    W, H, ts = 1920, 1080, 64
-    cams = [V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix(),
-            V.Camera(1.3, 0.2, 2.1, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix()]
-    cams = [cams[0], cams[0], cams[1], cams[0]]
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    try:
-        V.VolumeTexture.generate_standin(ctx, (256,) * 3)
-        pipe = V.RaycastPipeline(dt_scale=0.5)
-        singles = []
-        for c in cams:
-            ctx.set_camera_blob(c)
-            pipe.record(ctx)
-            singles.append(ctx.read_backbuffer().view(np.uint16).copy())
-        ctx.reset_step_counts()
-        V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT).record(ctx)  # camera 0 again
-        steps = ctx.read_steps()
-        _, rsteps, _ = O.render(cams[0], O.volume_standin_u8(256), W, H, dt_scale=0.5, tile=(640, 300, 640, 64))
-        assert (steps[300:364, 640:1280] == rsteps[300:364, 640:1280]).all()
-        B = len(cams)
-        frames = _synced(torch.zeros((B, H, W, 4), dtype=torch.float16, device="cuda"))
-        V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=ts)
-        ctx.sync()
-        got = frames.cpu().numpy().view(np.uint16)
-        for j in range(B):
-            assert (got[j] == singles[j]).all(), ("batch", j)
-        nr, k = 8, 2
-        ctx.set_root_skip(k)
-        cap = V.partition_slots(W, H, ts, nr, k)
-        gathered = None
-        for r in range(nr):
-            buf = _synced(torch.zeros((cap, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
-            bid, act = V.render_batch(ctx, pipe, cams, buf.data_ptr(), tile_size=ts, rank=r, nranks=nr, compact=True, slot_capacity=cap)
-            if gathered is None:
-                gathered = _synced(torch.zeros((nr, act, B, ts, ts, 4), dtype=torch.float16, device="cuda"))
-            ctx.sync()
-            gathered[r] = buf[:act]
-        frames.zero_()
-        torch.cuda.synchronize()  # torch's copies and fill (its own stream) before the library reads / writes them
-        V.untile_batch(ctx, bid, gathered.data_ptr(), act, frames.data_ptr())
-        ctx.sync()
-        got = frames.cpu().numpy().view(np.uint16)
-        for j in range(B):
-            assert (got[j] == singles[j]).all(), ("partition", j)
-    finally:
-        ctx.close()
-
-
-def test_batch_tile_renderer_over_rccl_world1(V, O):
-    """The N > 1 driver (vokselis_amd.dist.BatchTileRenderer) as a world of one over the library's own RCCL
-    communicator (vk_comm_init_rank / vk_gather_tiles): batches of 4 frames, a new camera every frame, a partial
-    batch at the end; every delivered frame bitwise equal to vk_render's frame for that camera."""
-    import torch
-    import torch.distributed as dist
-
-    from vokselis_amd.dist import BatchTileRenderer
-
-    created = False
-    if not dist.is_initialized():
-        import os
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=0, world_size=1)
-        created = True
-    W, H = 640, 360
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-    try:
-        V.VolumeTexture.generate_standin(ctx, (128,) * 3)
-        cams = _orbit_cameras(V, 11, W / H)
-        pipe = V.RaycastPipeline(dt_scale=0.5)
-        want = []
-        for c in cams:
-            ctx.set_camera_blob(c)
-            pipe.record(ctx)
-            want.append(ctx.read_backbuffer().view(np.uint16).copy())
-        got = {}
-
-        def on_batch(first, count, frames):
-            f = frames.cpu().numpy().view(np.uint16)
-            for j in range(count):
-                got[first + j] = f[j].copy()
-
-        with torch.cuda.stream(torch.cuda.Stream()):
-            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="rccl", on_batch=on_batch)
-            for c in cams:
-                r.submit(c)
-            r.close()
-            ctx.set_stream(None)
-        assert sorted(got) == list(range(11))
-        for k in range(11):
-            assert (got[k] == want[k]).all(), k
-        # driven from torch's default stream: the renderer makes (and enters) a stream of its own
-        got.clear()
-        r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="rccl", on_batch=on_batch)
-        assert r.march_stream.cuda_stream != 0
-        for c in cams:
-            r.submit(c)
-        r.close()
-        ctx.set_stream(None)
-        assert sorted(got) == list(range(11))
-        for k in range(11):
-            assert (got[k] == want[k]).all(), k
-    finally:
-        ctx.close()
-        if created:
-            dist.destroy_process_group()
-
-
-def _btr_two_ranks_worker(rank, world, port, q):
-    """One of two processes sharing cuda:0: the production BatchTileRenderer with rank/world = (rank, 2); only the
-    wire differs (gloo through host memory -- RCCL refuses two ranks on one device)."""
-    import os
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    import vokselis_amd as V
-    from vokselis_amd.dist import BatchTileRenderer
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        W, H = 640, 360
-        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA16F)
-        V.VolumeTexture.generate_standin(ctx, (128,) * 3)
-        cams = [V.Camera(1.0 + 0.03 * k, 0.5 - 0.05 * k, 1.0 + 0.3 * k, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for k in range(11)]
-        pipe = V.RaycastPipeline(dt_scale=0.5)
-        want = []
-        for c in cams:  # (both ranks: with a rotating root either may be handed a batch)
-            ctx.set_camera_blob(c)
-            pipe.record(ctx)
-            want.append(ctx.read_backbuffer().view(np.uint16).copy())
-        bad, seen = [], []
-
-        def on_batch(first, count, frames):
-            f = frames.cpu().numpy().view(np.uint16)
-            for j in range(count):
-                seen.append(first + j)
-                if not (f[j] == want[first + j]).all():
-                    bad.append(first + j)
-
-        with torch.cuda.stream(torch.cuda.Stream()):
-            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, transport="torch", via_host=True, on_batch=on_batch if rank == 0 else None)
-            for c in cams:
-                r.submit(c)
-            r.close()
-            ctx.set_stream(None)
-        fixed = (list(seen), list(bad))
-        del seen[:], bad[:]
-        # the same stream of frames with a rotating root: launch g is assembled on rank g mod 2
-        with torch.cuda.stream(torch.cuda.Stream()):
-            r = BatchTileRenderer(ctx, pipe, tile_size=64, batch=4, root="rotate", transport="torch", via_host=True, on_batch=on_batch)
-            assert r.root_skip == 0
-            for c in cams:
-                r.submit(c)
-            r.close()
-            ctx.set_stream(None)
-        ctx.close()
-        q.put((rank, fixed[0], fixed[1], list(seen), list(bad)))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_batch_tile_renderer_two_ranks_one_gpu(V, O):
-    """The N > 1 driver with two real ranks (two processes on this GPU): every frame's tiles dealt to both, batches of
-    4 frames with a different camera each, a partial batch; every frame delivered on the root bitwise equal to vk_render's."""
-    import socket
-
-    import torch.multiprocessing as mp
-
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    procs = [mpc.Process(target=_btr_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p_ in procs:
-        p_.start()
-    for p_ in procs:
-        p_.join(300)
-        assert p_.exitcode == 0
-    got = sorted(q.get(timeout=10) for _ in range(2))
-    assert got[0][0] == 0 and got[0][1] == list(range(11)) and got[0][2] == [], got
-    assert got[1][0] == 1 and got[1][1] == [], got
-    # rotating root: launches 0 and 2 (frames 0-3, 8-10) land on rank 0, launch 1 (frames 4-7) on rank 1, all bitwise equal
-    assert got[0][3] == [0, 1, 2, 3, 8, 9, 10] and got[0][4] == [], got
-    assert got[1][3] == [4, 5, 6, 7] and got[1][4] == [], got
-
-
-def test_group_api_and_plain_c_consumer(V, O, tmp_path):
-    """vk_group_* (one process, one context per GPU, ncclCommInitAll) on the GPUs this box has, and a plain-C program
-    (tests/cabi_smoke.c, gcc, no C++ / HIP headers) linked against the library: both must reproduce vk_render."""
-    import ctypes as C
-    import os
-    import subprocess
-
-    import torch
-
-    L = V.native.lib()
-    W, H = 320, 200
-    n_gpus = torch.cuda.device_count()
-    ords = (C.c_int * n_gpus)(*range(n_gpus))
-    g = C.c_void_p()
-    assert L.vk_group_create(n_gpus, ords, C.byref(g)) == 0
-    try:
-        assert L.vk_group_size(g) == n_gpus
-        vol = O.volume_standin_u8(48)
-        for i in range(n_gpus):
-            c = C.c_void_p(L.vk_group_ctx(g, i))
-            V.native.check(c, L.vk_backbuffer_resize(c, W, H, V.OUT_RGBA32F))
-            V.native.check(c, L.vk_volume_upload(c, vol.ctypes.data, None, 48, 48, 48, V.FMT_R8_UNORM, V.LAYOUT_AUTO))
-        cams = _orbit_cameras(V, 5, W / H)
-        root = C.c_void_p(L.vk_group_ctx(g, 0))
-        out = C.c_void_p()
-        V.native.check(root, L.vk_device_alloc(root, 5 * W * H * 16, C.byref(out)))
-        rc = L.vk_group_render(g, V.MODE_NAIVE_TRILINEAR, 5, b"".join(cams), 32, 0.5, 0, out)
-        assert rc == 0, L.vk_group_last_error(g)
-        assert L.vk_group_sync(g) == 0
-        got = np.empty((5, H, W, 4), np.float32)
-        V.native.check(root, L.vk_device_download(root, got.ctypes.data, out, got.nbytes))
-        V.native.check(root, L.vk_device_free(root, out))
-    finally:
-        L.vk_group_destroy(g)
-    for k, cam in enumerate(cams):
-        img, _, _ = gpu_render(V, cam, vol, W, H, dt=0.5, want_steps=False)
-        assert (img.view(np.uint32) == got[k].view(np.uint32)).all(), k
-    # the plain-C consumer
-    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "cabi_smoke")
-    lib_dir = os.path.join(root_dir, "vokselis_amd", "_lib")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root_dir, "include"), os.path.join(root_dir, "tests", "cabi_smoke.c"),
-                    "-L", lib_dir, "-lvokselis_hip", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe], check=True)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "cabi_smoke: OK" in r.stdout, r.stdout
-
-
 def test_f16_volume(V, O, golden, cameras):
     g = golden["naive_f16_64x64"]
     vol = O.volume_fog_f16(32)
@@ -746,25 +196,6 @@ def test_f16_volume(V, O, golden, cameras):
     ref, rsteps, rsamp = O.render(cameras["bonsai_1x1"], core, 96, 96, dt_scale=0.5)
     img, steps, (s_ref, s_samp) = gpu_render(V, cameras["bonsai_1x1"], core, 96, 96, dt=0.5)
     assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all() and s_samp == int(rsamp.sum())
-
-
-def _render_with_params(V, cam, vol, W, H, dt, layout, params=(), flags=0):
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        for k, v in params:
-            ctx.set_param(k, v)
-        V.VolumeTexture(ctx, vol, layout=layout)
-        ctx.set_camera_blob(cam)
-        ctx.reset_step_counts()
-        V.RaycastPipeline(dt_scale=dt, flags=flags | V.RENDER_COUNT).record(ctx)
-        img, steps = ctx.read_backbuffer(), ctx.read_steps()
-        census = ctx.simt_census()
-        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
-        V.RaycastPipeline(dt_scale=dt, flags=flags).record(ctx)
-        assert (ctx.read_backbuffer().view(np.uint32) == img.view(np.uint32)).all(), "production kernel differs from the instrumented one"
-        return img, steps, census
-    finally:
-        ctx.close()
 
 
 def test_staged_bricks_equal_linear_bitwise(V, O, golden_volumes):
@@ -984,346 +415,6 @@ def test_skip_fuzz_cameras_dims_dt(V, O):
         assert ma == int(rsamp.sum()) and np.abs(a - ref).max() <= TOL, (trial, dims, dt)
 
 
-def test_compute_nearest_mode(V, O, golden, cameras):
-    """raycast_compute.wgsl `single` and `tile` (A10-A12) against the golden vectors."""
-    g = golden["compute_128x72"]
-    den, nrm = g["density"].view(np.float16), g["normals"].view(np.float16)
-    # AUTO / PACKED: bricked 16-byte (density, normals) records, pipelined kernel; LINEAR: the two dense volumes
-    first = None
-    for lay in (V.LAYOUT_AUTO, V.LAYOUT_PACKED, V.LAYOUT_LINEAR):
-        img, steps, _ = gpu_render(V, cameras["xor_16x9"], den, 128, 72, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay)
-        assert np.abs(img - g["rgba"]).max() <= TOL and (steps == g["steps"]).all(), lay
-        first = img if first is None else first
-        assert (img.view(np.uint32) == first.view(np.uint32)).all(), "the record layout changes no bit"
-    # non-multiple-of-4 dims, a tile that hangs off the image, and long steps (speculative request far outside); the second volume has
-    # holes of exactly zero opacity with NaN normals in them (what the xor generator writes where the gradient vanishes), negative
-    # opacities and lone contributing voxels: the record kernel's skip map must not change a bit or a count
-    rng = np.random.default_rng(3)
-    d2 = rng.random((19, 10, 33, 4), np.float32).astype(np.float16); n2 = (rng.random((19, 10, 33, 4), np.float32) * 2 - 1).astype(np.float16)
-    d3 = rng.random((40, 27, 33, 4), np.float32); n3 = (rng.random((40, 27, 33, 4), np.float32) * 2 - 1)
-    hole = rng.random((40, 27, 33)) < 0.97
-    hole[10:30, 5:20, 8:25] = True
-    d3[..., 3][hole] = np.where(rng.random(int(hole.sum())) < 0.5, 0.0, -0.25)
-    n3[hole & (rng.random((40, 27, 33)) < 0.5)] = np.nan
-    d3[20, 12, 16, 3] = 0.9  # a lone voxel deep inside the hole
-    d3, n3 = d3.astype(np.float16), n3.astype(np.float16)
-    for (dv, nv) in ((d2, n2), (d3, n3)):
-        for dt in (1.0, 7.5, 0.3):
-            ref, rsteps, _ = O.render(cameras["xor_16x9"], dv, 96, 54, mode=O.MODE_COMPUTE_NEAREST, volume2=nv, dt_scale=dt)
-            got = {}
-            for lay, fl in ((V.LAYOUT_PACKED, 0), (V.LAYOUT_PACKED, V.RENDER_NO_SKIP), (V.LAYOUT_LINEAR, 0)):
-                img, steps, (sr, ss) = gpu_render(V, cameras["xor_16x9"], dv, 96, 54, vol2=nv, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt, flags=fl)
-                assert np.abs(img - ref).max() <= TOL and (steps == rsteps).all(), (dt, lay, fl)
-                got[(lay, fl)] = (img, ss)
-            assert (got[(V.LAYOUT_PACKED, 0)][0].view(np.uint32) == got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][0].view(np.uint32)).all(), dt
-            assert (got[(V.LAYOUT_PACKED, 0)][0].view(np.uint32) == got[(V.LAYOUT_LINEAR, 0)][0].view(np.uint32)).all(), dt
-            if dv is d3:
-                assert got[(V.LAYOUT_PACKED, 0)][1] <= got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][1] and (dt > 1.0 or got[(V.LAYOUT_PACKED, 0)][1] < got[(V.LAYOUT_PACKED, V.RENDER_NO_SKIP)][1]), dt  # (a wave-level affair: only the big hole is walked, and not with 9.6 voxels per step)
-    # the reference's tile loop: (H/256+1) x (W/256+1) offsets, here with 64-px tiles incl. off-screen ones
-    ctx = V.Context(128, 72, backbuffer=(128, 72), out_format=V.OUT_RGBA32F)
-    try:
-        V.VolumeTexture(ctx, den, nrm)
-        ctx.set_camera_blob(cameras["xor_16x9"])
-        pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST)
-        for y in range(72 // 64 + 1):
-            for x in range(128 // 64 + 1):
-                pipe.record(ctx, (x * 64, y * 64, 64, 64))
-        assert np.abs(ctx.read_backbuffer() - g["rgba"]).max() <= TOL
-    finally:
-        ctx.close()
-
-
-def test_compute_fuzz_cameras_dims_dt(V, O):
-    """Seeded fuzz of the compute twin's record kernel (request ring + exact skipping): random dims, blobs with exactly-zero and negative
-    opacity around them and NaN normals in the holes, cameras outside / inside / axis-aligned, image sizes and dt_scale.  Skip == no skip ==
-    the literal twin bitwise, iteration counts identical to the oracle; the same frames in one launch of several (the ring's other shape)."""
-    import torch
-
-    rng = np.random.default_rng(20261004)
-    for trial in range(12):
-        dims = tuple(int(x) for x in rng.integers(8, 48, 3))  # (nx, ny, nz)
-        W, H = int(rng.integers(32, 96)), int(rng.integers(32, 96))
-        z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
-        den = rng.random(x.shape + (4,), np.float32)
-        op = np.where(rng.random(x.shape) < 0.5, 0.0, -0.25).astype(np.float32)
-        for _ in range(3):
-            c = rng.uniform(0.2, 0.8, 3) * np.array(dims); rad = rng.uniform(2, 0.35 * min(dims))
-            d2 = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2
-            op = np.where(d2 < rad * rad, rng.uniform(0.2, 1.0), op)
-        den[..., 3] = op
-        nrm = (rng.random(x.shape + (4,), np.float32) * 2 - 1)
-        nrm[(op <= 0) & (rng.random(x.shape) < 0.5)] = np.nan
-        den, nrm = den.astype(np.float16), nrm.astype(np.float16)
-        kind = trial % 3
-        if kind == 0:
-            cam_args = (float(rng.uniform(2.0, 4.0)), float(rng.uniform(-1.3, 1.3)), float(rng.uniform(0, 6.28)), (0.0, 0.0, 0.0), W / H)
-        elif kind == 1:  # eye inside the box
-            cam_args = (float(rng.uniform(0.1, 0.6)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0, 6.28)), tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3)), W / H)
-        else:            # axis-aligned
-            cam_args = (3.0, 0.0, float(rng.integers(0, 4)) * 1.5707963, (0.0, 0.0, 0.0), 1.0)
-        dt = float(rng.choice([0.3, 1.0, 2.5]))
-        cam = O.camera_blob(*cam_args)
-        ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm, dt_scale=dt)
-        got = []
-        for lay, fl in ((V.LAYOUT_PACKED, 0), (V.LAYOUT_PACKED, V.RENDER_NO_SKIP), (V.LAYOUT_LINEAR, 0)):
-            img, steps, _ = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay, dt=dt, flags=fl)
-            assert (steps == rsteps).all() and np.abs(img - ref).max() <= TOL, (trial, dims, cam_args, dt, lay, fl)
-            got.append(img)
-        assert (got[0].view(np.uint32) == got[1].view(np.uint32)).all() and (got[0].view(np.uint32) == got[2].view(np.uint32)).all(), (trial, dims, cam_args, dt)
-        # three frames in one launch against the three single launches
-        cams = [cam] + [O.camera_blob(cam_args[0], cam_args[1], cam_args[2] + 0.3 * k, cam_args[3], cam_args[4]) for k in (1, 2)]
-        ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-        try:
-            V.VolumeTexture(ctx, den, nrm, layout=V.LAYOUT_PACKED)
-            pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, dt_scale=dt)
-            singles = []
-            for c in cams:
-                ctx.set_camera_blob(c); pipe.record(ctx); singles.append(ctx.read_backbuffer().copy())
-            assert (singles[0].view(np.uint32) == got[0].view(np.uint32)).all(), (trial, "the default policy's frame")
-            frames = _synced(torch.zeros((3, H, W, 4), dtype=torch.float32, device="cuda"))
-            V.render_batch(ctx, pipe, cams, frames.data_ptr(), tile_size=32)
-            ctx.sync()
-            out = frames.cpu().numpy()
-            for k in range(3):
-                assert (out[k].view(np.uint32) == singles[k].view(np.uint32)).all(), (trial, dims, cam_args, dt, "frame", k)
-        finally:
-            ctx.close()
-
-
-def test_procedural_mode(V, O, golden, cameras):
-    """C3: no volume, density from xor.wgsl's noise_volume at the sample position.  Trip counts are
-    integer work and must be identical; RGBA within 1e-4 (measured ~1e-7: the specified sine is shared)."""
-    g = golden["procedural_96x54"]
-    ctx = V.Context(96, 54, backbuffer=(96, 54), out_format=V.OUT_RGBA32F)
-    try:
-        ctx.set_camera_blob(cameras["xor_16x9"])          # no volume uploaded, Uniform.time = 0
-        for dt, kr, ks in ((1.0, "rgba", "steps"), (2.5, "rgba_dt2p5", "steps_dt2p5")):
-            ctx.reset_step_counts()
-            V.RaycastPipeline(V.MODE_PROCEDURAL, dt_scale=dt, flags=V.RENDER_COUNT).record(ctx)
-            img, steps = ctx.read_backbuffer(), ctx.read_steps()
-            assert (steps == g[ks]).all()
-            assert np.abs(img - g[kr]).max() <= TOL
-            assert ctx.step_counts()[0] == int(g[ks].astype(np.int64).sum())
-        # a tile that hangs off the image, uninstrumented, against the oracle at the same time value
-        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
-        V.RaycastPipeline(V.MODE_PROCEDURAL).record(ctx, (64, 32, 64, 64))
-        ref, _ = O.render_procedural(cameras["xor_16x9"], 96, 54, tile=(64, 32, 64, 64))
-        img = ctx.read_backbuffer()
-        assert np.abs(img[32:, 64:] - ref[32:, 64:]).max() <= TOL
-    finally:
-        ctx.close()
-    # larger frame, other camera, nonzero Uniform.time (xor.wgsl's un.time)
-    W, H = 320, 180
-    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H)
-    ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        ctx.global_uniform.time = 0.75
-        V.native.check(ctx.handle, V.native.lib().vk_set_uniform(ctx.handle, ctx.global_uniform.to_bytes()))
-        ctx.set_camera_blob(cam.get_proj_view_matrix())
-        V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_COUNT).record(ctx)
-        img, steps = ctx.read_backbuffer(), ctx.read_steps()
-        ref, rsteps = O.render_procedural(cam.get_proj_view_matrix(), W, H, time=0.75)
-        assert (steps == rsteps).all() and np.abs(img - ref).max() <= TOL
-    finally:
-        ctx.close()
-
-
-def test_error_behaviour(V, O, cameras, golden_volumes):
-    ctx = V.Context(64, 64, backbuffer=(64, 64), out_format=V.OUT_RGBA32F)
-    try:
-        pipe = V.RaycastPipeline()
-        with pytest.raises(V.VokselisError, match="no volume"):
-            pipe.record(ctx)
-        V.VolumeTexture(ctx, golden_volumes["standin"])
-        with pytest.raises(V.VokselisError, match="no camera"):
-            pipe.record(ctx)
-        ctx.set_camera_blob(cameras["bonsai_1x1"])
-        with pytest.raises(V.VokselisError, match="dt_scale"):
-            V.RaycastPipeline(dt_scale=0.0).record(ctx)
-        with pytest.raises(V.VokselisError, match="COMPUTE_NEAREST"):
-            V.RaycastPipeline(V.MODE_COMPUTE_NEAREST).record(ctx)
-        bad = np.frombuffer(cameras["bonsai_1x1"], np.float32).copy(); bad[5] = np.nan
-        with pytest.raises(V.VokselisError, match="non-finite"):
-            ctx.set_camera_blob(bad.tobytes())
-        with pytest.raises(V.VokselisError, match="no camera"):  # a rejected blob does not linger
-            pipe.record(ctx)
-        with pytest.raises(ValueError, match="144 bytes"):  # a short buffer never reaches the C side
-            ctx.set_camera_blob(cameras["bonsai_1x1"][:100])
-        ctx.set_camera_blob(cameras["bonsai_1x1"])
-        pipe.record(ctx, (0, 0, 0, 0))  # empty tile is a no-op
-        info = ctx.get_info()
-        assert info["gfx950"] and info["compute_units"] == 256
-        # the wire format of a partition's tiles: an enum of two, 16 or 12 bytes per rgba32f pixel
-        with pytest.raises(V.VokselisError, match="VK_WIRE"):
-            ctx.set_wire(5)
-        assert ctx.wire_pixel_bytes == 16
-        ctx.set_wire(V.WIRE_RGB)
-        assert ctx.wire_pixel_bytes == 12
-        ctx.set_wire(V.WIRE_RGBA)
-        with pytest.raises(V.VokselisError, match="trip_log_cap"):
-            ctx.set_param("trip_log_cap", 12)  # (a multiple of 8)
-    finally:
-        ctx.close()
-
-
-def test_headless_demo_loop(V, O):
-    """The reference's frame order: Context.update -> Demo.update -> Demo.render (src/lib.rs:75-79,178-181)."""
-    vol = O.volume_standin_u8(64)
-    calls = []
-
-    class Bonsai(V.Demo):
-        @classmethod
-        def init(cls, ctx):
-            self = cls()
-            self.volume_texture = V.VolumeTexture(ctx, vol)
-            self.pipeline = V.RaycastPipeline(V.MODE_NAIVE_TRILINEAR, dt_scale=1.0)
-            calls.append("init")
-            return self
-
-        def update(self, ctx):
-            calls.append("update")
-
-        def render(self, ctx):
-            calls.append("render")
-            self.pipeline.record(ctx)
-
-    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 160 / 90)
-    ctx, demo = V.run_headless(Bonsai, frames=3, camera=cam, width=160, height=90, backbuffer=(160, 90), out_format=V.OUT_RGBA32F)
-    try:
-        assert calls == ["init"] + ["update", "render"] * 3
-        ref, _, _ = O.render(cam.get_proj_view_matrix(), vol, 160, 90)
-        assert np.abs(ctx.read_backbuffer() - ref).max() <= TOL
-        buf, dims = ctx.capture_frame()  # run_headless presents after every Demo.render, like the reference
-        assert len(buf) == dims.linear_size() and dims.padded_bytes_per_row == 768
-    finally:
-        ctx.close()
-
-
-def test_cpp_host_bonsai_example(V, O, tmp_path):
-    """The compiled C++ host (vokselis_amd/host: Context / Demo / run_headless / bonsai) drives the same
-    C-ABI; its captured frame matches the oracle's frame after the same 8-bit quantisation."""
-    import os
-    import subprocess
-
-    import __graft_entry__ as g
-
-    g.build_host()
-    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "bonsai")
-    ppm = tmp_path / "bonsai.ppm"
-    r = subprocess.run([exe, "--frames", "3", "--size", "320x180", "--dt", "1.0", "--ppm", str(ppm)], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    assert "Avg frame time" in r.stdout and "gfx950" in r.stdout
-    raw = ppm.read_bytes()
-    hdr, data = raw.split(b"\n255\n", 1)
-    assert hdr == b"P6\n320 180"
-    img = np.frombuffer(data, np.uint8).reshape(180, 320, 3).astype(np.int32)
-    cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 320 / 180).get_proj_view_matrix()
-    ref, _, _ = O.render(cam, O.volume_standin_u8(256), 320, 180, dt_scale=1.0)
-    # the surface is rgba16f: quantise the oracle through f16 first, like the backbuffer, then present
-    ref16 = O.rgba32f_to_rgba16f(ref).view(np.float16).astype(np.float32)
-    want = O.present(ref16, 320, 180)[..., :3].astype(np.int32)
-    d = np.abs(img - want)
-    assert d.max() <= 1 and (d == 0).mean() > 0.995
-    # the hot path's own surface: the C++ host builds byte-identical camera blobs (one builder, DESIGN 2.1), so its
-    # f32 frame matches the oracle at the north star's 1e-4 and the kernel's trip counts are the oracle's
-    rgba, stp = tmp_path / "rgba.bin", tmp_path / "steps.bin"
-    r = subprocess.run([exe, "--frames", "1", "--size", "320x180", "--dt", "1.0", "--f32", "--dump-rgba", str(rgba), "--dump-steps", str(stp)],
-                       capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    got = np.fromfile(rgba, np.float32).reshape(180, 320, 4)
-    gsteps = np.fromfile(stp, np.uint32).reshape(180, 320)
-    ref, rsteps, _ = O.render(O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 320 / 180), O.volume_standin_u8(256), 320, 180, dt_scale=1.0)
-    assert np.abs(got - ref).max() <= TOL and (gsteps == rsteps).all()
-    # the same frames through the group API on the GPUs of this box
-    import torch
-    r = subprocess.run([exe, "--gpus", str(torch.cuda.device_count()), "--frames", "16", "--batch", "4", "--size", "320x180"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "Avg frame time" in r.stdout, r.stdout + r.stderr
-    # a missing GPU library / device is an error exit, not a silent fallback
-    r = subprocess.run([exe, "--raw", "/nonexistent.raw", "--frames", "1"], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "cannot open" in r.stderr
-
-
-def test_present_pass_and_capture_frame(V, O):
-    """Next rows N1/N2: present.wgsl (bilinear resample, ACESFilm, branch-free sRGB, Rgba8) and
-    capture_frame's byte layout (even-rounded size, 256-B row pitch)."""
-    vol = O.volume_standin_u8(64)
-    for (bw, bh), (w, h) in [((160, 90), (160, 90)), ((160, 90), (213, 121)), ((128, 72), (64, 36)), ((96, 96), (95, 33))]:
-        cam = V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), w / h)
-        for fmt in (V.OUT_RGBA16F, V.OUT_RGBA32F):
-            ctx = V.Context(w, h, cam, backbuffer=(bw, bh), out_format=fmt)
-            try:
-                V.VolumeTexture(ctx, vol)
-                ctx.update()
-                V.RaycastPipeline(dt_scale=1.0).record(ctx)
-                ctx.render()
-                buf, dims = ctx.capture_frame()
-                assert (dims.width, dims.height) == (w - w % 2, h - h % 2) and dims.padded_bytes_per_row % 256 == 0
-                assert len(buf) == dims.linear_size()
-                rows = np.frombuffer(buf, np.uint8).reshape(dims.height, dims.padded_bytes_per_row)
-                got = rows[:, :dims.unpadded_bytes_per_row].reshape(dims.height, dims.width, 4).astype(np.int32)
-                assert (rows[:, dims.unpadded_bytes_per_row:] == 0).all()
-                want = O.present(ctx.read_backbuffer().astype(np.float32), w, h)[:dims.height, :dims.width].astype(np.int32)
-                d = np.abs(got - want)
-                assert d.max() <= 1 and (d == 0).mean() > 0.995, ((bw, bh), (w, h), fmt, d.max(), (d == 0).mean())
-                assert (got[..., 3] == 255).all()
-            finally:
-                ctx.close()
-
-
-def test_xor_generator_and_example(V, O, tmp_path):
-    """Next rows N3/N4: shaders/xor.wgsl on the device is bit-identical to the oracle's generator (the
-    hash's sine is specified), and the xor example (generator + compute raycast, SinglePass and Tile
-    modes) reproduces the oracle's frame."""
-    import os
-    import subprocess
-
-    import __graft_entry__ as g
-
-    n, W, H = 64, 320, 180
-    den, nrm = O.volume_xor(n, 0.0)
-    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix()
-    ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
-    assert (rsteps > 0).mean() > 0.1
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        V.VolumeTexture.generate_xor(ctx, (n, n, n), 0.0)
-        ctx.set_camera_blob(cam)
-        V.RaycastPipeline(V.MODE_COMPUTE_NEAREST, flags=V.RENDER_COUNT).record(ctx)
-        img, steps = ctx.read_backbuffer(), ctx.read_steps()
-        assert (steps == rsteps).all()           # identical volumes -> identical trip counts
-        assert np.abs(img - ref).max() <= TOL
-        # device-generated == host-uploaded oracle volume, bit for bit
-        V.VolumeTexture(ctx, den, nrm)
-        V.RaycastPipeline(V.MODE_COMPUTE_NEAREST).record(ctx)
-        assert (ctx.read_backbuffer() == img).all()
-    finally:
-        ctx.close()
-    # the compiled example, both modes of examples/xor/main.rs:14-18
-    g.build_host()
-    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "xor")
-    ref16 = O.rgba32f_to_rgba16f(ref).view(np.float16).astype(np.float32)
-    want = O.present(ref16, W, H)[..., :3].astype(np.int32)
-    for mode in ("single", "tile"):
-        ppm = tmp_path / f"xor_{mode}.ppm"
-        r = subprocess.run([exe, "--frames", "2", "--size", f"{W}x{H}", "--volume", str(n), "--mode", mode, "--ppm", str(ppm)],
-                           capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0, r.stderr
-        data = ppm.read_bytes().split(b"\n255\n", 1)[1]
-        got = np.frombuffer(data, np.uint8).reshape(H, W, 3).astype(np.int32)
-        d = np.abs(got - want)
-        assert d.max() <= 2 and (d == 0).mean() > 0.99, (mode, d.max(), (d == 0).mean())
-    # the C3 surrogate through the compiled host: no volume, un.time pinned, presented like any other frame
-    refp, _ = O.render_procedural(cam, W, H, time=0.5)
-    wantp = O.present(O.rgba32f_to_rgba16f(refp).view(np.float16).astype(np.float32), W, H)[..., :3].astype(np.int32)
-    ppm = tmp_path / "xor_procedural.ppm"
-    r = subprocess.run([exe, "--frames", "2", "--size", f"{W}x{H}", "--mode", "procedural", "--time", "0.5", "--ppm", str(ppm)],
-                       capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    gotp = np.frombuffer(ppm.read_bytes().split(b"\n255\n", 1)[1], np.uint8).reshape(H, W, 3).astype(np.int32)
-    dp = np.abs(gotp - wantp)
-    assert dp.max() <= 2 and (dp == 0).mean() > 0.99, (dp.max(), (dp == 0).mean())
-
-
 def test_large_volume_layouts_agree(V, O):
     """Beyond the cache-resident sizes: a 640^3 u8 fog (262 M voxels) rendered through four independent
     layouts/kernels (9^3 dense bricks, 2x2 quads, 8-B cells, dense linear) gives bitwise-identical frames and
@@ -1464,327 +555,6 @@ def test_baseline_configs_dense_core_full_size(V, O, name, n, f16, W, H, seed, t
     lit, lsteps, _ = O.render(cam, host, W, H, dt_scale=0.5, tile=tile, flags=O.FLAG_LITERAL_WGSL)
     assert (steps["auto"][ys, xs] == lsteps[ys, xs]).all(), (name, "literal trips", int((steps["auto"][ys, xs] != lsteps[ys, xs]).sum()))
     assert np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max() <= 1e-5, (name, np.abs(imgs["auto"][ys, xs] - lit[ys, xs]).max())
-
-
-def test_raw_loader_round_trip(V, O, tmp_path):
-    """The drop-in loaders for the reference's `bonsai_256x256x256_uint8.raw` (volume_texture.rs:33 include_bytes!, absent
-    from the checkout): a synthetic .raw written to disk and loaded through VolumeTexture.from_raw (Python host) and
-    `bonsai --raw` (C++ host) renders exactly like the same bytes uploaded directly; a short file is an error."""
-    import os
-    import subprocess
-
-    import __graft_entry__ as g
-
-    vol = O.volume_standin_u8((128, 128, 64))  # 1 MiB
-    small = tmp_path / "vol_128x128x64_uint8.raw"
-    vol.tofile(small)
-    cam = O.camera_blob(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), 1.5)
-    want, wsteps, _ = gpu_render(V, cam, vol, 192, 128, dt=0.5)
-    ctx = V.Context(192, 128, backbuffer=(192, 128), out_format=V.OUT_RGBA32F)
-    try:
-        vt = V.VolumeTexture.from_raw(ctx, str(small), dims=(128, 128, 64))
-        assert vt.dims == (128, 128, 64)
-        ctx.set_camera_blob(cam)
-        V.RaycastPipeline(dt_scale=0.5, flags=V.RENDER_COUNT | V.RENDER_FORCE_SKIP).record(ctx)
-        assert (ctx.read_backbuffer().view(np.uint32) == want.view(np.uint32)).all() and (ctx.read_steps() == wsteps).all()
-        with pytest.raises(ValueError):
-            V.VolumeTexture.from_raw(ctx, str(small), dims=(256, 256, 256))
-    finally:
-        ctx.close()
-    # C++ host: the stand-in written as the reference's 16 MiB file gives the frame the built-in generator gives
-    g.build_host()
-    exe = os.path.join(g.ROOT, "vokselis_amd", "_lib", "bonsai")
-    big = tmp_path / "bonsai_256x256x256_uint8.raw"
-    O.volume_standin_u8(256).tofile(big)
-    outs = []
-    for extra in ([], ["--raw", str(big)]):
-        f = tmp_path / ("rgba%d.bin" % len(outs))
-        r = subprocess.run([exe, "--frames", "1", "--size", "256x144", "--f32", "--dump-rgba", str(f)] + extra, capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0, r.stderr
-        outs.append(np.fromfile(f, np.float32))
-    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all() and outs[0].max() > 0
-
-
-def test_procedural_partition(V, O):
-    """PROCEDURAL needs no volume: the partition calls accept it on a context without one, use the same tile order as
-    the render call (one order, not two), and partition + un-tile reproduces the frame."""
-    import torch
-
-    W, H, ts = 160, 96, 32
-    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H)
-    ctx = V.Context(W, H, cam, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        ctx.update()
-        pipe = V.RaycastPipeline(V.MODE_PROCEDURAL, dt_scale=4.0)
-        pipe.record(ctx)
-        want = ctx.read_backbuffer().copy()
-        act, slots = ctx.partition_active(ts, 2, V.MODE_PROCEDURAL)
-        assert act == 15 and slots == 8
-        order = ctx.partition_order(ts, V.MODE_PROCEDURAL)
-        assert sorted(order.tolist()) == list(range(15))
-        cap = V.partition_slots(W, H, ts, 2)
-        gathered = _synced(torch.zeros((2, cap, ts, ts, 4), device="cuda"))
-        for r in range(2):
-            pipe.record_partition(ctx, ts, r, 2, gathered[r].data_ptr())
-        V.native.check(ctx.handle, V.native.lib().vk_backbuffer_clear(ctx.handle))
-        V.native.check(ctx.handle, V.native.lib().vk_untile(ctx.handle, gathered.data_ptr(), ts, 2, cap))
-        assert (ctx.read_backbuffer().view(np.uint32) == want.view(np.uint32)).all()
-    finally:
-        ctx.close()
-
-
-@pytest.mark.parametrize("how", ["plain", "torchrun"])
-def test_bench_multi_rank_flow_rehearsal(V, O, how):
-    """bench.py's N > 1 flow end to end with two ranks -- both on this one GPU, rendezvous over gloo, tiles through
-    torch.distributed (rehearsal): the weighted deal, the pipelined gather + un-tile, max-over-ranks timing, the contiguous
-    >= 100-frame window and the JSON contract.
-      plain:    `python bench.py --gpus 2 ...` typed exactly like the N = 1 line -- bench.py starts its own ranks as a child
-                torch.distributed.run (and, seeing one GPU for two ranks, rehearses);
-      torchrun: the launch line the driver uses for N > 1.
-    (The library's RCCL communicator needs one GPU per rank: world 1 in test_batch_tile_renderer_over_rccl_world1, its
-    multi-peer branches under the stand-in of test_multi_peer_branches_under_fake_rccl, real peers on the driver's 8-GPU node.)"""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VK_BENCH_REHEARSAL")}
-    if how == "plain":
-        cmd = [sys.executable] + tail
-    else:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        env["VK_BENCH_REHEARSAL"] = "1"
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["unit"] == "Mray-steps/s" and d["value"] > 0
-    assert d["config"]["s_ref_config_camera"] == 148393048  # the C2 frame, as at N = 1
-    assert "rehearsal" in d and d["config"]["transport"].startswith("torch.distributed")
-    # exactly K steps are timed; a step is one launch of frames_per_launch frames: one contiguous window of >= 100 frames (SURVEY 8d)
-    assert d["launches_per_region"] == 5 and d["timed_frames"] == 5 * d["frames_per_launch"] >= 100
-    assert abs(d["ms_per_step"] * d["steps"] * 1e-3 / d["timed_region_s"] - 1.0) < 1e-5 and abs(d["ms_per_frame"] * d["frames_per_launch"] / d["ms_per_step"] - 1.0) < 1e-9
-    assert abs(d["timed_region_s"] * d["value"] * 1e6 / (d["config"]["s_ref_per_frame"] * d["timed_frames"]) - 1.0) < 1e-5
-    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "still_camera", "rotating_root"):
-        assert key in d, key
-    assert d["rotating_root"]["value"] > 0 and d["config"]["wire"]["format"] == "rgb" and d["config"]["wire"]["bytes_per_pixel"] == 6
-
-
-@pytest.mark.parametrize("what", ["config_c5", "c5_at_n"])
-def test_bench_c5_two_rank_rehearsal(V, O, what):
-    """BASELINE's 8-GPU configuration (C5: 2048^3 u8, 3840x2160, replicated volume, framebuffer tiles over the ranks) through bench.py's N > 1
-    flow with two ranks on this one GPU (2 x 26 GB of bricks fit): the JSON contract of
-      config_c5: `bench.py --gpus 2 --config c5` -- C5 as the line's own workload;
-      c5_at_n:   `bench.py --gpus 2` -- the C2 line the driver's scaling run produces, with C5 through the same partition + gather + un-tile in
-                 extras.c5_at_n (fixed root and rotating root; a time-limited child job started once the C2 ranks have left their process group),
-                 so that the first real 8-GPU run yields BASELINE's own 8-GPU configuration too.
-    A test of the flow, not a measurement.  Generalises the reference's tile loop, examples/xor/main.rs:77-95,235-254."""
-    import json
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
-    cmd += ["--config", "c5", "--no-extras"] if what == "config_c5" else ["--no-rotate"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VK_BENCH_REHEARSAL")}
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mray-steps/s" and d["value"] > 0 and "rehearsal" in d
-    assert d["launches_per_region"] == 4 and d["timed_frames"] == 4 * d["frames_per_launch"] and d["timed_region_s"] > 0
-    assert abs(d["timed_region_s"] / d["steps"] * 1e3 / d["ms_per_step"] - 1.0) < 1e-5
-    for key in ("metric", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
-        assert key in d, key
-    if what == "config_c5":
-        assert d["config"]["workload"].startswith("C5") and d["frames_per_launch"] * d["launches_per_region"] >= d["timed_frames"]
-        # the fog never reaches the early-out: every ray takes its nominal iterations, ~6.2e9 of them per frame (SURVEY 8d)
-        assert 5.5e9 < d["config"]["s_ref_config_camera"] < 6.8e9 and d["config"]["s_sampled_config_camera"] == d["config"]["s_ref_config_camera"]
-        assert d["rotating_root"]["value"] > 0
-    else:
-        assert d["config"]["s_ref_config_camera"] == 148393048
-        c5 = d["extras"]["c5_at_n"]  # (a child `bench.py --gpus 2 --config c5` with a time limit: it cannot take the C2 line down)
-        assert "error" not in c5, c5
-        assert c5["workload"].startswith("C5") and c5["n_gpus"] == 2 and 5.5e9 < c5["s_ref_per_frame"] < 6.8e9 and "rehearsal" in c5
-        for mode in ("fixed_root", "rotating_root"):
-            assert c5[mode]["value"] > 0 and c5[mode]["ms_per_frame"] > 0, c5[mode]
-
-
-def test_multi_peer_branches_under_fake_rccl(V, O):
-    """The branches that only run with more than one peer -- vk_group_render's n > 1 path and vk_gather_tiles' root branch --
-    executed on this one GPU through a single-process stand-in for RCCL (tests/fake_rccl.cpp, bound via VK_RCCL_LIB): n = 2, 3, 8
-    contexts, root_skip 0 / 2 / 3, every frame bitwise equal to vk_render's.  In a child process, so that this process keeps
-    the real RCCL for the other tests.  Generalises the reference's tile loop, examples/xor/main.rs:235-254."""
-    import os
-    import subprocess
-    import sys
-
-    import __graft_entry__ as g
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VK_RCCL_LIB=g.build_fake_rccl())
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "shim_multi_rank_check.py")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "shim_multi_rank_check: OK" in r.stdout, r.stdout
-    assert r.stdout.count("vk_group_render n=") == 9 and r.stdout.count("vk_gather_tiles n=") == 5, r.stdout
-
-
-# ---------------------------------------------------------------------------------------------
-# round 4: the reference-held pin and the full-size cases bench.py times
-
-
-def _captured_rgb(ctx):
-    buf, dims = ctx.capture_frame()
-    rows = np.frombuffer(buf, np.uint8).reshape(dims.height, dims.padded_bytes_per_row)
-    return rows[:, :dims.unpadded_bytes_per_row].reshape(dims.height, dims.width, 4)
-
-
-def test_volume_png_pin_hip(V, O):
-    """The reference's `volume.png` through the HIP path alone: vk_volume_generate_xor (xor.wgsl, t = 0) -> vk_render
-    COMPUTE_NEAREST into the 1280x720 backbuffer -> vk_present to the capture's 958x1050 window, at the camera
-    oracle/volume_png.py fitted.  Against the committed oracle frame (<= 1 LSB) and against the capture (same loose bars
-    as the oracle's own CPU test: background exact, blurred correlation, silhouette box, side of the pink light)."""
-    from oracle import volume_png as VP
-
-    pin = VP.load_pin()
-    cap = pin["capture_blur_ds"].astype(np.float32)
-    want = VP.load_oracle_frame().astype(np.int32)
-    for fmt, lsb, same in ((V.OUT_RGBA32F, 1, 0.995), (V.OUT_RGBA16F, 2, 0.97)):  # rgba16f is the reference's own surface (hdr_backbuffer.rs:10)
-        ctx = V.Context(VP.WIN_W, VP.WIN_H, backbuffer=(VP.BB_W, VP.BB_H), out_format=fmt)
-        try:
-            V.VolumeTexture.generate_xor(ctx, (VP.XOR_N,) * 3, 0.0)
-            ctx.set_camera_blob(pin["camera"].tobytes())
-            V.RaycastPipeline(V.MODE_COMPUTE_NEAREST).record(ctx)
-            ctx.render()
-            got = _captured_rgb(ctx)
-        finally:
-            ctx.close()
-        assert got.shape == (VP.WIN_H, VP.WIN_W, 4) and (got[..., 3] == 255).all()
-        assert (got[0, 0, :3] == VP.BACKGROUND).all() and (got[-1, -1, :3] == VP.BACKGROUND).all()
-        d = np.abs(got[..., :3].astype(np.int32) - want)
-        assert d.max() <= lsb and (d == 0).mean() > same, (fmt, d.max(), (d == 0).mean())
-        m = VP.metrics(got, cap)
-        VP.check(m)
-        assert abs(m["corr"] - float(pin["corr"])) < 5e-3 and abs(m["mean_abs"] - float(pin["mean_abs"])) < 0.05, m
-
-
-def test_bonsai_png_pin_hip(V, O):
-    """The naive path's reference-held pin through the HIP kernels (oracle/bonsai_png.py): the palette curve -- uniform volumes v = 0 .. 255
-    under a saturating ray -- rendered by vk_render equals the oracle's, the colours of the reference's `bonsai.png` lie inside its hull, and
-    the capture's greenest colour is the HIP curve's point for v = 179 to one LSB."""
-    from oracle import bonsai_png as BP
-
-    pin = BP.load_pin()
-    W, H = 16, 9
-    ctx = V.Context(W, H, V.Camera(1.0, 0.5, 1.0, (0.5, 0.5, 0.5), W / H), backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        pipe = V.RaycastPipeline(dt_scale=1.0)
-
-        def one(v):
-            V.VolumeTexture(ctx, np.full((32, 32, 32), v, np.uint8))
-            ctx.update()
-            pipe.record(ctx)
-            return ctx.read_backbuffer()[H // 2, W // 2].copy()
-
-        curve = BP.curve_backbuffer(one)
-    finally:
-        ctx.close()
-    ref = BP.oracle_curve()
-    assert np.abs(curve - ref).max() <= TOL
-    hull = BP.hull_of(curve)
-    both = np.vstack([pin["sample"], pin["extremes"]])
-    assert BP.inside_share(both, hull, BP.decode_double_srgb) >= BP.BAR_INSIDE
-    assert BP.inside_share(both, hull, BP.decode_aces_srgb) <= BP.BAR_INSIDE_ACES
-    v, d = BP.nearest_on_curve(BP.GREENEST, curve)
-    assert d <= BP.BAR_GREENEST and 170 <= v <= 190, (v, d)
-
-
-def test_xor_example_full_size(V, O):
-    """The reference's own xor configuration at its own size: 256^3 pair volume, 1280x720, camera (3, -0.5, 1, 0)
-    (examples/xor/main.rs:232-233,273-279) -- the frame bench.py times as `xor_compute_nearest_720p`.  Every pixel and every
-    trip count against the oracle, through the record kernel (AUTO) and the literal twin (LINEAR), `single` and the 3 x 6
-    `tile` loop with its wholly off-screen column (examples/xor/main.rs:77-95,235-254)."""
-    W, H, n = 1280, 720, 256
-    den, nrm = O.volume_xor(n, 0.0)
-    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix()
-    ref, rsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm)
-    s_ref = int(rsteps.astype(np.int64).sum())
-    assert s_ref == 21175162 and rsteps.max() <= 293 and abs(int((rsteps > 0).sum()) - 180_000) < 5_000  # SURVEY A11
-    frames, sampled = {}, {}
-    for name, lay, fl in (("records", V.LAYOUT_AUTO, 0), ("records_noskip", V.LAYOUT_AUTO, V.RENDER_NO_SKIP), ("literal", V.LAYOUT_LINEAR, 0)):
-        img, steps, (sr, ss) = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, layout=lay, flags=fl)
-        assert (steps == rsteps).all() and sr == s_ref, name
-        assert np.abs(img - ref).max() <= TOL, (name, np.abs(img - ref).max())
-        frames[name], sampled[name] = img, ss
-    assert (frames["records"].view(np.uint32) == frames["literal"].view(np.uint32)).all()
-    # the record kernel against raycast_compute.wgsl:62-97 AS WRITTEN (VO_FLAG_LITERAL_WGSL: pow(a, 3.0) through powf, both smoothsteps
-    # with their divide, nothing fused): every pixel of the example's own frame -- no trip count moves, <= 1e-5 per channel
-    lit, lsteps, _ = O.render(cam, den, W, H, mode=O.MODE_COMPUTE_NEAREST, volume2=nrm, flags=O.FLAG_LITERAL_WGSL)
-    assert (lsteps == rsteps).all(), int((lsteps != rsteps).sum())
-    assert np.abs(frames["records"] - lit).max() <= 1e-5, np.abs(frames["records"] - lit).max()
-    # exact empty-space skipping of the record kernel (round 4): not a bit changes, and the steps that fetch and shade are those whose
-    # record can contribute plus a rim of one or two voxels -- the blob fills half of the cube, a ray sees far less of it
-    assert (frames["records"].view(np.uint32) == frames["records_noskip"].view(np.uint32)).all()
-    assert sampled["records_noskip"] == s_ref and sampled["literal"] == s_ref
-    a3 = den[..., 3].astype(np.float32) ** 3
-    assert 0.3 < float((a3 > 0).mean()) < 0.6
-    assert sampled["records"] < 0.75 * s_ref, (sampled["records"], s_ref)
-    # three 64x64 tiles by name: centre, silhouette, hanging off the right edge
-    hit = rsteps > 0
-    ys, xs = np.nonzero(hit)
-    sil_x = int(xs.min()) - 32
-    for tx, ty in ((W // 2 - 32, H // 2 - 32), (sil_x, H // 2 - 32), (W - 32, H // 2 - 32)):
-        t_img, t_steps, _ = gpu_render(V, cam, den, W, H, vol2=nrm, mode=V.MODE_COMPUTE_NEAREST, tile=(tx, ty, 64, 64))
-        x1 = min(tx + 64, W)
-        assert np.abs(t_img[ty:ty + 64, tx:x1] - ref[ty:ty + 64, tx:x1]).max() <= TOL
-        assert (t_steps[ty:ty + 64, tx:x1] == rsteps[ty:ty + 64, tx:x1]).all()
-    # the device generator + the reference's tile loop: TILE_SIZE 256, (H/256+1) x (W/256+1) = 3 x 6 offsets
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        V.VolumeTexture.generate_xor(ctx, (n,) * 3, 0.0)
-        ctx.set_camera_blob(cam)
-        pipe = V.RaycastPipeline(V.MODE_COMPUTE_NEAREST)
-        for y in range(H // 256 + 1):
-            for x in range(W // 256 + 1):
-                pipe.record(ctx, (x * 256, y * 256, 256, 256))
-        assert (ctx.read_backbuffer().view(np.uint32) == frames["records"].view(np.uint32)).all()
-    finally:
-        ctx.close()
-
-
-def test_procedural_full_size_tiles(V, O):
-    """C3 at the size bench.py times it (1920x1080): one interior and one silhouette 64x64 tile and a 64-row strip through the
-    middle against `render_procedural`; trip counts identical."""
-    W, H = 1920, 1080
-    cam = V.Camera(3.0, -0.5, 1.0, (0.0, 0.0, 0.0), W / H).get_proj_view_matrix()
-    ctx = V.Context(W, H, backbuffer=(W, H), out_format=V.OUT_RGBA32F)
-    try:
-        ctx.set_camera_blob(cam)
-        ctx.reset_step_counts()
-        V.RaycastPipeline(V.MODE_PROCEDURAL, flags=V.RENDER_COUNT).record(ctx)
-        img, steps = ctx.read_backbuffer(), ctx.read_steps()
-    finally:
-        ctx.close()
-    row = steps[H // 2]
-    xs = np.nonzero(row)[0]
-    assert xs.size > 300
-    tiles = [(W // 2 - 32, H // 2 - 32, 64, 64), (int(xs.min()) - 32, H // 2 - 32, 64, 64), (0, H // 2 - 32, W, 64)]
-    for (tx, ty, tw, th) in tiles:
-        ref, rsteps = O.render_procedural(cam, W, H, tile=(tx, ty, tw, th))
-        sl = (slice(ty, ty + th), slice(tx, tx + tw))
-        assert (steps[sl] == rsteps[sl]).all(), (tx, ty)
-        assert np.abs(img[sl] - ref[sl]).max() <= TOL, (tx, ty, np.abs(img[sl] - ref[sl]).max())
-        # the literal reading (powf, the march's and xor.wgsl:59's smoothsteps with their divide): no trip count moves, <= 1e-5
-        lit, lsteps = O.render_procedural(cam, W, H, tile=(tx, ty, tw, th), flags=O.FLAG_LITERAL_WGSL)
-        assert (steps[sl] == lsteps[sl]).all(), (tx, ty, "literal trips")
-        assert np.abs(img[sl] - lit[sl]).max() <= 1e-5, (tx, ty, np.abs(img[sl] - lit[sl]).max())
-    assert rsteps[H // 2 - 32:H // 2 + 32].max() > 150
 
 
 def test_rgba16f_full_size_c2(V, O):

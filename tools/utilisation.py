@@ -30,7 +30,7 @@ CASES = [
     ("C5: staged u8, 3840x2160, single frame (one window per 256-thread group)", "c5", "raymarch_staged_group_kernel<10, 1, false>", "raymarch_staged_group_kernelILi10ELi1ELb0E", 50, 2048 ** 3),
     ("C4: staged f16, 1920x1080, single frame", "c4", "raymarch_staged_kernel<11, 1, false>", "raymarch_staged_kernelILi11ELi1ELb0E", 50, 2 * 1024 ** 3),
     ("compute twin (16-byte records, exact skipping, 6-buffer request ring), xor 1280x720, single frame", "xor", "raymarch_compute_records_kernel<1, false, true, 6, 1>", "raymarch_compute_records_kernelILi1ELb0ELb1ELi6ELi1E", None, None),
-    ("C3: procedural, 1920x1080, single frame", "c3", "raymarch_procedural_kernel<1, false>", "raymarch_procedural_kernelILi1ELb0E", None, None),
+    ("C3: procedural, 1920x1080, single frame", "c3", "raymarch_procedural_kernel<1, false, false>", "raymarch_procedural_kernelILi1ELb0ELb0E", None, None),
 ]
 
 
