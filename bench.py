@@ -440,6 +440,34 @@ def latency_section(V, torch, ctx, stream, cfg, flags, s_ref_still, s_sampled_st
             stream_of["raycast"][key] = frame_stream_ms(ctx, p1, cam_list, n, k)
             stream_of["raycast_then_present"][key] = frame_stream_ms(ctx, p1, cam_list, n, k, present=True)
             stream_of["raycast_present_fused"][key] = frame_stream_ms(ctx, pf_, cam_list, n, k)
+        # the recorder's loop (src/lib.rs:196-199: capture_frame of every frame): the presented Rgba8 image of every frame read back over
+        # PCIe into pinned host memory, three frames behind the one being recorded (K = 4, present fused) -- the PCIe-INCLUSIVE rate
+        try:
+            import ctypes as C
+
+            dims = V.ImageDimentions.new(W, H, 256)
+            host = torch.empty(dims.linear_size(), dtype=torch.uint8, pin_memory=True)
+            ids = []
+
+            def recorder_window(m):
+                for j in range(m):
+                    ctx.set_camera_blob(cam_list[j % len(cam_list)])
+                    ids.append(ctx.frame_begin())
+                    pf_.record(ctx)
+                    ctx.frame_end()
+                    if len(ids) > 3:
+                        V.native.check(ctx.handle, V.native.lib().vk_frame_capture(ctx.handle, ids[-4], C.c_void_p(host.data_ptr()), host.numel(), None, None, None))
+                ctx.sync()
+
+            recorder_window(16)
+            t0 = time.perf_counter()
+            recorder_window(64)
+            ms_rec = (time.perf_counter() - t0) / 64 * 1e3
+            stream_of["recorder_loop"] = {"ms_per_frame": ms_rec, "host_GBps": dims.linear_size() / (ms_rec * 1e-3) / 1e9,
+                                          "note": "in_flight_4, present fused, vk_frame_capture of every frame (8.3 MB of Rgba8 per 1080p frame) into pinned host memory, "
+                                                  "three frames behind: bound by the copy over PCIe, the raycast hides under it"}
+        except Exception as e:  # noqa: BLE001
+            stream_of["recorder_loop"] = {"error": repr(e)}
         ctx.frames_in_flight(1)
         best = min(stream_of["raycast"], key=lambda k_: stream_of["raycast"][k_])
         msb = stream_of["raycast"][best]

@@ -151,7 +151,8 @@ int vk_capture_frame(vk_ctx *ctx, void *dst, size_t dst_bytes, uint32_t *out_wid
     if (dst_bytes < (size_t)padded * h) return fail(ctx, VK_ERR_INVALID, "vk_capture_frame: destination smaller than padded_bytes_per_row * height");
     if (w == 0 || h == 0) return VK_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    std::memset(dst, 0, (size_t)padded * h);
+    if (padded != unpadded)  // the row padding reads as zeros (a 1920-wide frame has none: 7680 = 30 x 256)
+        for (uint32_t y = 0; y < h; y++) std::memset(static_cast<unsigned char *>(dst) + (size_t)y * padded + unpadded, 0, padded - unpadded);
     HIP_TRY(ctx, hipMemcpy2DAsync(dst, padded, ctx->rgba8, (size_t)ctx->present_w * 4, unpadded, h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VK_OK;
