@@ -94,6 +94,37 @@ int main(void) {
         fprintf(stderr, "vk_render_batch frames differ from vk_render\n");
         return 1;
     }
+    /* the interactive shape (ABI 5): three frames in flight, the present fused into the pass; the frame that stays in its slot is the frame
+     * above bit for bit, and its presented Rgba8 image is the one vk_present makes of it, to one 8-bit step */
+    {
+        uint64_t id[4] = {0, 0, 0, 0};
+        uint32_t cw = 0, ch = 0, pitch = 0;
+        CHECK(ctx, vk_present(ctx, W, H, 0));  /* of the frame rendered above */
+        CHECK(ctx, vk_capture_frame(ctx, NULL, 0, &cw, &ch, &pitch));  /* sizes: even-rounded, rows padded to 256 bytes (src/utils/mod.rs:99-117) */
+        if (cw != W || ch != H || pitch != 512) { fprintf(stderr, "capture dims %ux%u pitch %u\n", cw, ch, pitch); return 1; }
+        unsigned char *shot_a = (unsigned char *)malloc((size_t)pitch * ch), *shot_b = (unsigned char *)malloc((size_t)pitch * ch);
+        if (!shot_a || !shot_b) return 1;
+        CHECK(ctx, vk_capture_frame(ctx, shot_a, (size_t)pitch * ch, NULL, NULL, NULL));
+        CHECK(ctx, vk_ctx_frames_in_flight(ctx, 3));
+        for (int k = 0; k < 4; k++) {
+            CHECK(ctx, vk_set_camera(ctx, cam));
+            CHECK(ctx, vk_frame_begin(ctx, &id[k]));
+            CHECK(ctx, vk_render(ctx, VK_MODE_NAIVE_TRILINEAR, 0, 0, W, H, 0.5f, VK_RENDER_PRESENT));
+            CHECK(ctx, vk_frame_end(ctx));
+        }
+        if (!(id[0] >= 1 && id[3] == id[0] + 3)) { fprintf(stderr, "frame ids %llu .. %llu\n", (unsigned long long)id[0], (unsigned long long)id[3]); return 1; }
+        if (vk_frame_readback(ctx, id[0], two, sizeof(float) * 4 * W) != VK_ERR_INVALID) { fprintf(stderr, "a frame whose slot was retaken could still be read\n"); return 1; }
+        CHECK(ctx, vk_frame_wait(ctx, id[0]));
+        CHECK(ctx, vk_frame_readback(ctx, id[2], two, sizeof(float) * 4 * W));
+        if (memcmp(one, two, sizeof(float) * 4 * W * H) != 0) { fprintf(stderr, "a frame in flight differs from vk_render's\n"); return 1; }
+        CHECK(ctx, vk_frame_capture(ctx, id[3], shot_b, (size_t)pitch * ch, NULL, NULL, NULL));
+        for (int i = 0; i < (int)(pitch * ch); i++) {
+            int d = (int)shot_a[i] - (int)shot_b[i];
+            if (d < -1 || d > 1) { fprintf(stderr, "fused present differs from vk_present by %d at byte %d\n", d, i); return 1; }
+        }
+        CHECK(ctx, vk_ctx_frames_in_flight(ctx, 1));
+        free(shot_a); free(shot_b);
+    }
     /* error behaviour across the boundary: codes, never aborts */
     if (vk_render(ctx, 77, 0, 0, W, H, 0.5f, 0) != VK_ERR_INVALID) { fprintf(stderr, "bad mode was accepted\n"); return 1; }
     if (vk_dispatch_optimal(1920, 8) != 240 || vk_dispatch_optimal(1081, 8) != 136) { fprintf(stderr, "dispatch_optimal\n"); return 1; }

@@ -4,7 +4,8 @@
 //          [--f32] [--dump-rgba file] [--dump-steps file]   parity surface (rgba32f) + per-pixel trip counts, raw
 //          [--gpus N] [--batch B] [--peer-direct]            the frame's tiles over N GPUs of this node (vk_group_*); --peer-direct: the GPUs
 //                                                            store into GPU 0's frames themselves instead of gather + un-tile
-//          [--in-flight K] [--orbit] [--fuse-present]                        K frames in flight (vk_ctx_frames_in_flight); --orbit: the camera turns by 2 pi / 1024 every frame
+//          [--in-flight K] [--orbit] [--fuse-present] [--record]                        K frames in flight (vk_ctx_frames_in_flight); --orbit: the camera turns by 2 pi / 1024 every frame;
+//                                                            --record: capture_frame of every frame, K - 1 frames behind (the recorder, src/lib.rs:196-199)
 //          [--camera-blobs orbits.txt out.bin]              no GPU: one 144-byte CameraUniform per "zoom pitch yaw tx ty tz aspect" line
 #include <cstdio>
 #include <algorithm>
@@ -107,7 +108,7 @@ static int dump_camera_blobs(const std::string &in, const std::string &out) {
 int main(int argc, char **argv) {
     uint32_t frames = 100, w = 1280, h = 720, batch = 8, in_flight = 1;
     int gpus = 0;
-    bool f32 = false, peer_direct = false, fuse_present = false;
+    bool f32 = false, peer_direct = false, fuse_present = false, record = false;
     std::string ppm, dump_rgba, dump_steps;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -125,6 +126,7 @@ int main(int argc, char **argv) {
         else if (a == "--in-flight") in_flight = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--orbit") g_orbit = true;
         else if (a == "--fuse-present") fuse_present = true;
+        else if (a == "--record") record = true;
         else if (a == "--batch") batch = (uint32_t)std::max(1, std::atoi(next()));
         else if (a == "--camera-blobs") { std::string in = next(); return dump_camera_blobs(in, next()); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -139,8 +141,19 @@ int main(int argc, char **argv) {
         ctx.fuse_present = fuse_present;  // (the present pass in the raycast pass's epilogue: VK_RENDER_PRESENT)
         std::printf("%s\n", ctx.get_info().c_str());
         double ms = 0;
-        auto demo = run_headless<Bonsai>(ctx, frames, &ms, in_flight);
+        // --record: the reference's recorder takes capture_frame() of every frame (src/lib.rs:196-199); with frames in flight it takes the frame
+        // K - 1 ids back -- finished or nearly so -- while the newer ones execute
+        std::vector<uint8_t> rec;
+        uint64_t recorded = 0, rec_sum = 0;
+        auto recorder = [&](Context &c, uint64_t id) {
+            if (!record || id < in_flight) return;
+            c.capture_frame_into(id - (in_flight - 1), rec);
+            recorded++;
+            rec_sum += rec[rec.size() / 2];
+        };
+        auto demo = run_headless<Bonsai>(ctx, frames, &ms, in_flight, recorder);
         std::printf("Avg frame time %.4fms over %u frames (%u in flight)\n", ms, frames, in_flight);  // src/utils/frame_counter.rs:23-24
+        if (record) std::printf("recorded %llu frames (probe byte sum %llu)\n", (unsigned long long)recorded, (unsigned long long)rec_sum);
         auto shot = ctx.capture_frame();
         uint64_t sum = 0;
         for (uint8_t b : shot.first) sum += b;

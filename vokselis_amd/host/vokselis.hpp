@@ -243,6 +243,11 @@ class Context {
         check(ctx_, vk_frame_capture(ctx_, id, out.data(), out.size(), nullptr, nullptr, nullptr));
         return {out, dims};
     }
+    void capture_frame_into(uint64_t id, std::vector<uint8_t> &out) {  // (the recorder's reused buffer)
+        ImageDimentions dims(width, height, 256);
+        if (out.size() != dims.linear_size()) out.assign(dims.linear_size(), 0);
+        check(ctx_, vk_frame_capture(ctx_, id, out.data(), out.size(), nullptr, nullptr, nullptr));
+    }
     std::string get_info() const {
         char name[256]; int cus = 0, is950 = 0; size_t mem = 0;
         check(ctx_, vk_device_info(ctx_, name, sizeof name, &cus, &is950, &mem));
@@ -351,8 +356,11 @@ struct Demo {
 
 // run::<D> (src/lib.rs:45-208) without the window: Context::update -> Demo::update -> Demo::render.
 // in_flight > 1: the loop runs up to that many frames ahead of the GPU, every frame on a surface of its own.
-template <class D>
-std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_frame_ms = nullptr, uint32_t in_flight = 1) {
+// on_frame(ctx, id), if given, runs after each frame has been submitted -- the place of the reference's recorder
+// (`if recording_status { context.capture_frame() ... }`, src/lib.rs:196-199), which with frames in flight captures a frame a few ids back.
+struct NoFrameHook { void operator()(Context &, uint64_t) const {} };
+template <class D, class OnFrame = NoFrameHook>
+std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_frame_ms = nullptr, uint32_t in_flight = 1, OnFrame on_frame = OnFrame()) {
     FrameCounter fc;
     if (in_flight > 1) ctx.frames_in_flight(in_flight);
     std::unique_ptr<D> demo = D::init(ctx);
@@ -362,10 +370,11 @@ std::unique_ptr<D> run_headless(Context &ctx, uint32_t frames, double *mean_fram
         ctx.update(fc);
         demo->update(ctx);
         fc.record();
-        ctx.frame_begin();
+        const uint64_t id = ctx.frame_begin();
         demo->render(ctx);
         ctx.render();  // src/lib.rs:178-182: demo.render, then context.render (present)
         ctx.frame_end();
+        on_frame(ctx, id);
     }
     ctx.sync();
     if (mean_frame_ms) *mean_frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames ? frames : 1);
