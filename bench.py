@@ -226,6 +226,19 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
         blobs = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(nb)]
         ms_b = time_launches(ctx, lambda: V.render_batch(ctx, p, blobs, fr.data_ptr(), tile_size=tile_of(cfg)), 3, warm=1) / nb
         del fr
+        # ... and one frame per vk_render, the camera turning, on one stream and with three / four frames in flight (vk_ctx_frames_in_flight)
+        stream_ms = {}
+        try:
+            orbit = [V.Camera(1.0, 0.5, 1.0 + 6.28318 * j / 1024, (0.5, 0.5, 0.5), W / H).get_proj_view_matrix() for j in range(16)]
+            nfr = 32 if key == "c4" else 12
+            for k in (0, 3, 4):
+                if k:
+                    ctx.frames_in_flight(k)
+                stream_ms["one_stream" if k == 0 else "in_flight_%d" % k] = frame_stream_ms(ctx, p, orbit, nfr, k)
+            ctx.frames_in_flight(1)
+        except Exception as e:  # noqa: BLE001
+            stream_ms = {"error": repr(e)}
+        ctx.set_camera_blob(cam.get_proj_view_matrix())
         dims = (V.native.C.c_uint32 * 3)()
         lay, nbytes = V.native.C.c_int(), V.native.C.c_size_t()
         V.native.check(ctx.handle, V.native.lib().vk_volume_info(ctx.handle, dims, None, V.native.C.byref(lay), V.native.C.byref(nbytes)))
@@ -257,6 +270,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
                 **({"algorithmic_frac_note": "8 B (u8) / 16 B (f16) per step over 8 TB/s: an accounting of the taps the LDS windows serve, not a bound; the HBM side is `physical_hbm`"} if staged else {}),
                 "volume_setup_s": setup, "dense_core": core,
                 "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, fkey: alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "frame_stream_ms_per_frame": stream_ms,
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
                 "volume_device_bytes": nbytes.value, "kernel": "vk::raymarch_staged_kernel" if lay.value == 6 else "vk::raymarch_naive_kernel"}
     finally:

@@ -1,7 +1,7 @@
 """Frames in flight in a few seconds: ms per frame of the one-vk_render-per-frame surface, every frame a new orbit camera, on one
 surface / one stream (today's vk_render loop) and on rings of K = 1..4 surfaces (vk_ctx_frames_in_flight), for C2 (bonsai stand-in
 256^3, 1080p, dt_scale 0.5) and the xor example's own frame (256^3 pair, 1280x720).  Wall time around N frames, best of three.
-usage: tools/fif_quick.py [--frames N] [--present | --fused]   (--present: vk_present after every vk_render; --fused: VK_RENDER_PRESENT)"""
+usage: tools/fif_quick.py [c4] [c5] [--frames N] [--present | --fused]   (--present: vk_present after every vk_render; --fused: VK_RENDER_PRESENT)"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,7 @@ def stream_of_frames(ctx, pipe, cams, frames_api):
                 ctx.render()
             if frames_api:
                 ctx.frame_end()
-    once(64)
+    once(min(64, n))
     ctx.sync()
     best, host = 1e9, 1e9
     for _ in range(3):
@@ -40,10 +40,15 @@ def stream_of_frames(ctx, pipe, cams, frames_api):
     return best, host
 
 
+big = [a for a in sys.argv[1:] if a in ("c4", "c5")]  # the beyond-cache configs instead of C2 / xor (fewer frames: a frame is milliseconds)
 out = {"lib": os.environ.get("VK_LIB", "product"), "params": os.environ.get("VK_PARAMS", ""), "frames": n, "present": "fused" if fused else present}
-for name, (w, h), mk, mode, dt, cam0 in (
-        ("c2", (1920, 1080), lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
-        ("xor720p", (1280, 720), lambda c: V.VolumeTexture.generate_xor(c, (256,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))):
+CASES = [("c2", (1920, 1080), lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
+         ("xor720p", (1280, 720), lambda c: V.VolumeTexture.generate_xor(c, (256,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))]
+if big:
+    n = min(n, 48)
+    CASES = [c for c in (("c4", (1920, 1080), lambda c: V.VolumeTexture.generate_fog(c, (1024,) * 3, fmt=V.FMT_R16_FLOAT, seed=0x5EED0004), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
+                         ("c5", (3840, 2160), lambda c: V.VolumeTexture.generate_fog(c, (2048,) * 3, fmt=V.FMT_R8_UNORM, seed=0x5EED0005), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)))) if c[0] in big]
+for name, (w, h), mk, mode, dt, cam0 in CASES:
     ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
     for kv in os.environ.get("VK_PARAMS", "").split(","):  # library knobs: VK_PARAMS=name=value,...
         if "=" in kv:
@@ -53,7 +58,7 @@ for name, (w, h), mk, mode, dt, cam0 in (
     cams = [V.Camera(z, p, y + 6.28318 * j / 1024, t, w / h).get_proj_view_matrix() for j in range(128)]
     pipe = V.RaycastPipeline(mode, dt_scale=dt, flags=V.RENDER_PRESENT if fused else 0)
     ctx.set_camera_blob(cams[0])
-    for _ in range(200):
+    for _ in range(8 if big else 200):
         pipe.record(ctx)  # clocks
     r5 = lambda t: (round(t[0], 5), round(t[1], 5))  # (ms per frame, of which the host spent submitting)
     res = {"plain": r5(stream_of_frames(ctx, pipe, cams, False))}

@@ -331,11 +331,14 @@ class BatchTileRenderer:
         if self.timeout_s is None:
             ev.synchronize()
             return
-        t_end = time.monotonic() + float(self.timeout_s)
+        t0 = time.monotonic()
+        t_end = t0 + float(self.timeout_s)
         while not ev.query():
-            if time.monotonic() > t_end:
+            now = time.monotonic()
+            if now > t_end:
                 self._lost(what)
-            time.sleep(2e-4)
+            if now - t0 > 2e-3:  # (a gather in its last microseconds is polled, not slept on: the next launch waits for this)
+                time.sleep(2e-4)
 
     def _launch(self):
         if self._dead:
