@@ -232,6 +232,7 @@ int vk_ctx_frames_in_flight(vk_ctx *ctx, uint32_t k) {
     if (!ctx) return VK_ERR_INVALID;
     if (k == 0 || k > VK_MAX_FRAMES_IN_FLIGHT) return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: k must be in [1, " + std::to_string(VK_MAX_FRAMES_IN_FLIGHT) + "]");
     if (ctx->fif_open) return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: a frame is open (vk_frame_end first)");
+    if (k > 1 && ctx->in_group) return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: a member of a vk_group renders the group's batches on the group's streams");
     if (k > 1 && ctx->stream != ctx->own_stream && ctx->fif_k == 1)
         return fail(ctx, VK_ERR_INVALID, "vk_ctx_frames_in_flight: the context runs on a caller's stream (vk_ctx_set_stream(ctx, NULL) first)");
     int drc = frames_drain(ctx);
