@@ -126,6 +126,35 @@ def test_frames_in_flight_tile_loop(V):
     assert frames[1][0].astype(np.float32)[..., :3].max() > 0.1  # (something was drawn)
 
 
+def test_crowded_ring_variants_are_bitwise_equal(V):
+    """A frame of a ring in which three frames execute (k = 4) is launched with the leaner kernel variants -- the naive march without probe-ahead,
+    the compute twin with its smallest request ring: the frames are those of one surface, bit for bit."""
+    cases = [("bonsai", 1920, 1080, lambda c: V.VolumeTexture.generate_standin(c, (256,) * 3), V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5))),
+             ("xor", 1280, 720, lambda c: V.VolumeTexture.generate_xor(c, (128,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)))]
+    for name, w, h, mk, mode, dt, (z, p, y, t) in cases:
+        cams = [V.Camera(z, p + 0.02 * j, y + 0.07 * j, t, w / h).get_proj_view_matrix() for j in range(6)]
+        pipe = V.RaycastPipeline(mode, dt_scale=dt)
+        ctx = V.Context(w, h, backbuffer=(w, h), out_format=V.OUT_RGBA16F)
+        try:
+            mk(ctx)
+            ref = []
+            for cb in cams:
+                ctx.set_camera_blob(cb)
+                pipe.record(ctx)
+                ref.append(ctx.read_backbuffer())
+            ctx.frames_in_flight(4)
+            ids = []
+            for cb in cams:
+                ctx.set_camera_blob(cb)
+                ids.append(ctx.frame_begin())
+                pipe.record(ctx)
+                ctx.frame_end()
+            for j in range(2, 6):
+                assert (ctx.read_frame(ids[j]).view(np.uint16) == ref[j].view(np.uint16)).all(), (name, j)
+        finally:
+            ctx.close()
+
+
 def test_frames_in_flight_misuse_is_an_error_code(V):
     import torch
 

@@ -307,7 +307,7 @@ int vk_frame_begin(vk_ctx *ctx, uint64_t *frame_id) {
     // and leave it to a lone frame while the host records the next ones (C2, k = 3, no limit: three kernels ran 48 % of the time, a lone one
     // 31 %, 0.089 ms per frame); with one frame held back the next starts the moment a frame ends, with no host latency in between
     // (0.080 at k = 3, 0.072 at k = 4 with the lean kernel; the xor frame 0.055 / 0.050; profiles/r06_frames_in_flight.txt).  fif_concurrent overrides k - 1.
-    const uint32_t conc = ctx->fif_concurrent ? ctx->fif_concurrent : (ctx->fif_k >= 3u ? ctx->fif_k - 1u : ctx->fif_k);
+    const uint32_t conc = frames_concurrent(ctx);
     if (ctx->fif_k > conc && s.id > conc) {
         const uint64_t before = s.id - conc;
         for (uint32_t i = 0; i < ctx->fif_k; i++)

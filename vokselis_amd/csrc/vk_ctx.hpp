@@ -171,6 +171,11 @@ inline int fail(vk_ctx *ctx, int code, const std::string &msg) {
         }                                                                                      \
     } while (0)
 
+// Frames in flight: how many of the ring's frames execute at once (vk_frame_begin holds the others back), and whether the launch being recorded
+// belongs to a frame of a CROWDED ring -- three executing (k = 4) -- where the machine is full and the leaner kernel variants win.
+inline uint32_t frames_concurrent(const vk_ctx *ctx) { return ctx->fif_concurrent ? ctx->fif_concurrent : (ctx->fif_k >= 3u ? ctx->fif_k - 1u : ctx->fif_k); }
+inline bool frames_crowded(const vk_ctx *ctx) { return ctx->fif_open && ctx->fif_k > 1u && frames_concurrent(ctx) >= 3u; }
+
 inline size_t px_bytes(int fmt) { return fmt == VK_OUT_RGBA16F ? 8 : 16; }
 // a pixel of a partition's compact tiles: the backbuffer's pixel, or its three colour channels (VK_WIRE_RGB)
 inline size_t wire_px_bytes(int fmt, int wire) { return wire == VK_WIRE_RGB ? px_bytes(fmt) / 4 * 3 : px_bytes(fmt); }

@@ -39,7 +39,9 @@ void launch_compute(vk_ctx *ctx, const LaunchDesc &L, const VolumeDesc &V, uint3
         // request buffers x revolutions of the ring per loop iteration (vk_compute.hpp; profiles/r04_compute_twin_skip_and_ring.txt): a launch of
         // one frame that does not fill the machine (720p: 14 400 waves) is its longest waves' chains and gains from the deeper ring; launches
         // that do (1080p: 32 400; several frames) from the longer loop body
-        const uint32_t ring = ctx->pair_ring ? ctx->pair_ring : ((L.n_frames > 1 || L.n_blocks >= 24000u) ? 42u : 6u);
+        // ... and a frame of a crowded ring of frames in flight (three executing) from the smallest ring: the xor 720p frame 0.0500 -> 0.0456 ms
+        // per frame at k = 4 with four buffers and one revolution (6: 0.0500, 4 x 2: 0.0502; on one stream 4 costs 1.5 %)
+        const uint32_t ring = ctx->pair_ring ? ctx->pair_ring : (frames_crowded(ctx) ? 4u : ((L.n_frames > 1 || L.n_blocks >= 24000u) ? 42u : 6u));
         if (!skip) launch_records<false, 4, 1>(ctx, L, V, grid, count);
         else if (ring == 42) launch_records<true, 4, 2>(ctx, L, V, grid, count);
         else if (ring == 6) launch_records<true, 6, 1>(ctx, L, V, grid, count);

@@ -25,8 +25,7 @@ uint32_t launch_flags(const vk_ctx *ctx, uint32_t render_flags, bool batch) {
     // probe ahead pays where a frame's waves run against their own dependent chains -- a lone single-frame launch (-11 %) -- and costs where the
     // machine is full (+6-8 % in batches).  A frame of a ring in which three frames execute at once (k = 4) is in the second case: C2 0.0768 ->
     // 0.0724 ms per frame with the leaner kernel there, 0.080 -> 0.088 at k = 3 where two execute (profiles/r06_frames_in_flight.txt)
-    const uint32_t conc = ctx->fif_concurrent ? ctx->fif_concurrent : (ctx->fif_k >= 3u ? ctx->fif_k - 1u : ctx->fif_k);
-    const bool crowded = ctx->fif_open && ctx->fif_k > 1u && conc >= 3u;
+    const bool crowded = frames_crowded(ctx);
     if (ctx->probe_ahead == 1u || (ctx->probe_ahead == 2u && !batch && !crowded)) f |= LF_PROBE_AHEAD;  // (dispatch_march drops it for dt_scale > 1.25)
     return f;
 }
