@@ -351,7 +351,7 @@ int vk_frame_info(vk_ctx *ctx, uint64_t frame_id, void **backbuffer, void **rgba
     return with_frame_slot(ctx, frame_id, "vk_frame_info", [&] {
         if (backbuffer) *backbuffer = ctx->backbuffer;
         if (rgba8) *rgba8 = ctx->rgba8;
-        if (complete) *complete = hipEventQuery(ctx->fif[ctx->fif_cur].done) == hipSuccess ? 1 : 0;
+        if (complete) { *complete = hipEventQuery(ctx->fif[ctx->fif_cur].done) == hipSuccess ? 1 : 0; (void)hipGetLastError(); }  // (hipErrorNotReady is an answer, not an error to find later)
         return (int)VK_OK;
     });
 }

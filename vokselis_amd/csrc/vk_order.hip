@@ -96,7 +96,7 @@ int order_ensure_device(vk_ctx *ctx) {
             for (uint32_t i = 0; i < ctx->fif_k; i++) if (ctx->fif[i].id == f) fs = &ctx->fif[i];
             if (!fs) ordered = true;
             else if (fs->ended) {
-                if (hipEventQuery(fs->done) != hipSuccess) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, fs->done, 0));
+                if (hipEventQuery(fs->done) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, fs->done, 0)); }
                 ordered = true;
             }
         }
@@ -127,6 +127,7 @@ int order_wait(vk_ctx *ctx) {
     const int s = ctx->ring_slot;
     if (s < 0 || ctx->ring_done[s] || ctx->stream == ctx->ring_stream[s]) return VK_OK;
     if (hipEventQuery(ctx->ring_ev[s]) == hipSuccess) { ctx->ring_done[s] = true; return VK_OK; }
+    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error for the launch that follows to find)
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ring_ev[s], 0));
     return VK_OK;
 }
