@@ -3,6 +3,8 @@
 // box through happy paths).  Every buffer below is a std::vector of EXACTLY the size the library allocates, so an index that strays is an
 // AddressSanitizer report; every conversion and shift is under UndefinedBehaviorSanitizer.
 //
+//   blocks:    logical_block and group_logical_block (the XCD-aware relabelling of workgroups, per wave and per 256-thread group) are bijections on
+//              whole runs; a group's four waves are the 2 x 2 neighbouring blocks of one tile.
 //   deal:      deal_pos / deal_owner / deal_rounds are inverse to each other and dense, for 1..8 ranks, root_skip 0, 2..16, 0..4000 positions.
 //   order:     tile_order is a permutation with the active tiles in front, inactive ones in index order, order_pos its inverse; NO pixel whose
 //              ray hits the box lies in an inactive tile (rays cast in double, 4 per tile + the tile corners), for cameras around, inside and
@@ -161,6 +163,45 @@ static void fuzz_deal() {
             // positions past the dealt ones never alias a dealt slot of the same rank
             for (uint32_t r = 0; r < N; r++) { const uint32_t p = deal_pos(r, per_rank[r], N, kk); CHECK(p >= tiles, "rank %u's next slot %u maps to dealt position %u", r, per_rank[r], p); }
         }
+}
+
+// ---- workgroup -> logical block: bijections on whole runs -----------------------------------------------------------------------------------
+static void fuzz_block_maps() {
+    const uint32_t runs = pick(1, 6);
+    {
+        const uint32_t n = runs * 512u;
+        std::vector<char> hit(n, 0);
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t lb = logical_block(b);
+            CHECK(lb < n && !hit[lb], "logical_block(%u) = %u (of %u)", b, lb, n);
+            if (lb < n) hit[lb] = 1;
+            // XCD b % 8 receives 64 consecutive logical blocks of the run of 512: one 64 x 64 tile
+            CHECK((lb & 511u) >> 6 == (b & 7u), "physical block %u (XCD %u) -> logical %u", b, b & 7u, lb);
+        }
+    }
+    static const uint32_t tss[] = {16, 32, 48, 64, 96, 128};
+    const uint32_t ts = tss[rnd() % 6], per_tile = (ts / 8) * (ts / 8);
+    // whole runs of 128 groups (512 blocks) that are also whole tiles
+    uint32_t n = 512u;
+    while (n % per_tile) n += 512u;
+    n *= runs;
+    std::vector<char> hit(n, 0);
+    for (uint32_t G = 0; G < n / 4u; G++) {
+        uint32_t lbs[4];
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t lb = lbs[w] = group_logical_block(G, w, ts);
+            CHECK(lb < n && !hit[lb], "group_logical_block(%u, %u, ts %u) = %u (of %u)", G, w, ts, lb, n);
+            if (lb < n) hit[lb] = 1;
+        }
+        // the four waves of a group: 2 x 2 neighbouring 8x8 blocks of one tile
+        const uint32_t sps = ts / 8, t0 = lbs[0] / per_tile, s0 = lbs[0] % per_tile, x0 = s0 % sps, y0 = s0 / sps;
+        CHECK((x0 & 1u) == 0 && (y0 & 1u) == 0, "group %u does not start on an even block (%u, %u)", G, x0, y0);
+        for (uint32_t w = 1; w < 4; w++) {
+            const uint32_t sw = lbs[w] % per_tile;
+            CHECK(lbs[w] / per_tile == t0 && sw % sps == x0 + (w & 1u) && sw / sps == y0 + (w >> 1), "group %u wave %u is not the 2 x 2 neighbour", G, w);
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) CHECK(hit[i], "block %u of %u is reached by no (group, wave) (ts %u)", i, n, ts);
 }
 
 // ---- order ------------------------------------------------------------------------------------------------------------------------------------
@@ -333,6 +374,7 @@ int main(int argc, char **argv) {
     if (!state) state = 1;
     for (long c = 0; c < cases; c++) {
         fuzz_deal();
+        fuzz_block_maps();
         fuzz_order();
         fuzz_order();
         fuzz_pipeline();

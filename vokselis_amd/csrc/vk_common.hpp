@@ -139,18 +139,10 @@ enum LaunchFlag : uint32_t {
 };
 
 // ---- block -> pixels -------------------------------------------------------------------------
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD's L2).  A
-// group of 512 consecutive physical blocks is mapped so that each XCD receives 64 consecutive
-// logical blocks = the 64 waves of one 64x64 pixel tile: neighbouring rays share an L2, while
-// successive tiles still spread over all XCDs (the frame is ~70 % empty, so contiguous bands
-// per XCD would not balance).  Speed only -- nothing depends on the placement.
+// logical_block / group_logical_block (vk_hostmath.hpp): the XCD-aware relabelling of workgroups.  Speed only -- nothing depends on the placement.
 // (A persistent variant -- one wave per hardware slot pulling blocks from per-XCD atomic queues --
 // balanced the per-SIMD work better (max/mean 1.62 -> 1.45) but lost 0.235 -> 0.35 ms to the
 // dequeue round trips of ~32 k mostly trivial blocks: tools/experiments/persistent_workqueue.patch.)
-__device__ __forceinline__ uint32_t logical_block(uint32_t b) {
-    uint32_t group = b >> 9, r = b & 511u;
-    return (group << 9) + ((r & 7u) << 6) + (r >> 3);
-}
 
 // (Dealing the tiles out SIMD by SIMD -- every SIMD one block from each of 8 tiles -- left the per-SIMD work
 // spread at max/mean 1.66: the spread is block-to-block variation inside tiles, not tile placement.

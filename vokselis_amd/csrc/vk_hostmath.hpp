@@ -49,6 +49,26 @@ VK_HD uint32_t deal_rounds(uint32_t tiles, uint32_t N, uint32_t k) {
     return r;
 }
 
+// ---- physical workgroup -> logical 8x8 block ---------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD's L2).  A group of 512 consecutive physical
+// blocks is mapped so that each XCD receives 64 consecutive logical blocks = the 64 waves of one 64x64 pixel tile: neighbouring
+// rays share an L2, while successive tiles still spread over all XCDs.  A bijection on every multiple of 512 (grids are padded to one).
+VK_HD uint32_t logical_block(uint32_t b) {
+    const uint32_t group = b >> 9, r = b & 511u;
+    return (group << 9) + ((r & 7u) << 6) + (r >> 3);
+}
+// The staged march's 256-thread groups: workgroup G (round-robin over the XCDs: a run of 128 consecutive groups gives every XCD the 16
+// groups of one 64 x 64 tile) and its wave -> the logical 8x8 block; the four waves of a group are the 2 x 2 neighbouring blocks of a tile
+// (tile edge a multiple of 16).  A bijection between (G, wave) and the blocks of whole runs of 128 groups.
+VK_HD uint32_t group_logical_block(uint32_t G, uint32_t wave, uint32_t ts) {
+    const uint32_t chunk = G >> 7, rr = G & 127u;
+    const uint32_t LG = (chunk << 7) + ((rr & 7u) << 4) + (rr >> 3);
+    const uint32_t sps = ts >> 3, per_tile = sps * sps, hq = sps >> 1;  // 8x8 blocks per tile edge (even), quads per tile edge
+    const uint32_t l4 = LG * 4u + wave, u = l4 % per_tile, q = u >> 2, w = u & 3u;
+    const uint32_t qy = q / hq, qx = q - qy * hq;
+    return (l4 - u) + (2u * qy + (w >> 1)) * sps + 2u * qx + (w & 1u);
+}
+
 // ---- a launch's logical block -> (slot, frame, 8x8 block inside the tile) -------------------------
 // Batched launches are position-major: (slot, frame) pairs with the frame running fastest, per_tile blocks each.  With
 // frame_runs the frame index is relabelled so that the 8 consecutive pairs the launch hands to the 8 XCDs are runs of

@@ -662,15 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     static_assert(VOL == VOL_S8U8 || VOL == VOL_S8F16, "staged layouts");
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blockIdx.x * kGroupWaves >= L.grid_march) { clear_inactive_strip<OUT>(L, blockIdx.x * kGroupWaves + wave - L.grid_march, lane); return; }  // group-uniform
-    uint32_t lb;
-    {
-        const uint32_t G = blockIdx.x, chunk = G >> 7, rr = G & 127u;
-        const uint32_t LG = (chunk << 7) + ((rr & 7u) << 4) + (rr >> 3);
-        const uint32_t sps = L.ts >> 3, per_tile = sps * sps, hq = sps >> 1;  // 8x8 blocks per tile edge (even), quads per tile edge
-        const uint32_t l4 = LG * kGroupWaves + wave, u = l4 % per_tile, q = u >> 2, w = u & 3u;
-        const uint32_t qy = q / hq, qx = q - qy * hq;
-        lb = (l4 - u) + (2u * qy + (w >> 1)) * sps + 2u * qx + (w & 1u);
-    }
+    const uint32_t lb = group_logical_block(blockIdx.x, wave, L.ts);  // (vk_hostmath.hpp; kGroupWaves == 4)
     if (lb >= L.n_blocks) return;  // group-uniform: n_blocks is a multiple of the blocks of a tile
     const FrameView fv = frame_view(L, lb);
     const PixelMap pm = map_pixel(L, fv, lane);
