@@ -367,10 +367,13 @@ int vk_step_counts_reset(vk_ctx *ctx);
  * out[0] wave-level march-loop iterations, out[1] wave-level skipped-step iterations,
  * out[2] wave-level sample executions, out[3] per-lane march-loop iterations (lookups). */
 int vk_simt_census(vk_ctx *ctx, uint64_t out[4]);
+/* Debug: override the tile order table of the last launch's partition (experiments on launch order): `order` is a permutation of
+ * the n tiles (position -> row-major tile id) that keeps the active tiles -- the leading vk_partition_active positions of the
+ * current order, the only ones a launch marches -- in front; anything else is VK_ERR_INVALID.  It stays until the partition's
+ * key (camera, volume, tile size, rectangle) changes.  The frame does not depend on the order. */
+int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n);
 /* Debug: per-8x8-block {first start, last end, HW_ID | XCC_ID << 32, work} of the next VK_RENDER_COUNT NAIVE
  * launch (s_memrealtime stamps).  enable != 0 arms it; out != NULL copies n_blocks quadruples back. */
-/* Debug: override the tile order table (experiments on launch order). */
-int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n);
 int vk_debug_wave_trace(vk_ctx *ctx, int enable, uint64_t *out, size_t n_blocks);
 /* Debug / tuning knobs of the staged march: "stage_cap_bytes" (LDS window per wave; 0 = default: 8192 for u8, 10240 for f16),
  * "stage_slab_cells" (a round is a slab of at most that many cells along the wave's major axis, default 8), "stage_copies_mask" (bit k: build the brick copy

@@ -210,7 +210,16 @@ int vk_debug_set_tile_order(vk_ctx *ctx, const uint32_t *order, uint32_t n) {
     // experiment hook: replace the current (already computed) order table; stays until the key changes
     if (!ctx || !order) return VK_ERR_INVALID;
     if (n != ctx->order.size()) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: no order of that size");
-    for (uint32_t q = 0; q < n; q++) if (order[q] >= n) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: not a permutation of the tiles");
+    {
+        std::vector<char> seen(n, 0);
+        for (uint32_t q = 0; q < n; q++) {
+            if (order[q] >= n || seen[order[q]]) return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: not a permutation of the tiles");
+            seen[order[q]] = 1;
+            // only the leading order_active positions are marched, the tiles behind them are cleared: the active tiles stay in front
+            if ((q < ctx->order_active) != (ctx->order_pos[order[q]] < ctx->order_active))
+                return fail(ctx, VK_ERR_INVALID, "vk_debug_set_tile_order: the active tiles (vk_partition_active) must stay the leading ones");
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipDeviceSynchronize());
