@@ -141,13 +141,13 @@ def test_timer_brackets_the_launches_between_begin_and_end(V):
             ctx.timer_end()
             return ctx.timer_elapsed_ms()
 
-        one = min(bracket(1) for _ in range(5))
-        eight = min(bracket(8) for _ in range(5))
+        one = min(bracket(1) for _ in range(7))
+        eight = min(bracket(8) for _ in range(7))
         assert 0.0 < one < 50.0
-        assert eight > 3.0 * one, (one, eight)  # eight launches in order on one stream
+        assert eight > 2.0 * one, (one, eight)  # eight launches, in order on one stream (a launch's fixed cost is paid once per bracket)
         assert eight < 8.0 * one + 1.0, (one, eight)
         # an empty bracket is (almost) nothing
-        assert 0.0 <= bracket(0) < one
+        assert 0.0 <= min(bracket(0) for _ in range(3)) < max(one, 0.05)
     finally:
         ctx.close()
 
