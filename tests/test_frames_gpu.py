@@ -285,6 +285,8 @@ def _fused_cases(V):
         # (name, w, h, volume, mode, dt, camera, tiles or None)
         ("bonsai 720p", 1280, 720, naive, V.MODE_NAIVE_TRILINEAR, 1.0, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
         ("bonsai 480x270", 480, 270, naive, V.MODE_NAIVE_TRILINEAR, 0.5, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
+        ("bonsai 203x117: ragged blocks on both edges", 203, 117, naive, V.MODE_NAIVE_TRILINEAR, 1.0, (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
+        ("xor 333x95", 333, 95, lambda c: V.VolumeTexture.generate_xor(c, (64,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)), None),
         ("staged", 320, 180, lambda c: V.VolumeTexture.generate_fog(c, (96,) * 3, layout=V.LAYOUT_STAGED, dense_core=True), V.MODE_NAIVE_TRILINEAR, 0.5,
          (1.0, 0.5, 1.0, (0.5, 0.5, 0.5)), None),
         ("xor single", 1280, 720, lambda c: V.VolumeTexture.generate_xor(c, (128,) * 3, 0.0), V.MODE_COMPUTE_NEAREST, 1.0, (3.0, -0.5, 1.0, (0.0, 0.0, 0.0)), None),
