@@ -52,6 +52,8 @@ def tile_of(cfg) -> int:
 
 
 PROF = "r06"  # prefix of the PMC-derived files under profiles/ this line quotes (tools/prof.sh, tools/pmc_traffic.py, tools/utilisation.py)
+# (a window per wave or one per 256-thread group of four waves, chosen per launch: vk_launch_staged.hip -- C5 and 4-frame C4 launches take the group kernel)
+STAGED_KERNELS = "vk::raymarch_staged_kernel | vk::raymarch_staged_group_kernel"
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling, same guide
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, max clock (same guide); an f32 full-rate wave64 instruction holds a SIMD for 2 cycles,
@@ -272,7 +274,7 @@ def big_config_extra(V, torch, local_rank, key, frames=6):
                 "batch": {"frames_per_launch": nb, "cameras": "consecutive frames of an orbit, yaw step 2pi/1024", "ms_per_frame": ms_b, "Mray_steps_per_s": s_ref / ms_b / 1e3, fkey: alg / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "frame_stream_ms_per_frame": stream_ms,
                 "layout": {6: "staged 8^3 bricks through LDS, 3 copies", 4: "dense 9^3 bricks", 3: "cells, f16 pairs", 2: "cells"}.get(lay.value, str(lay.value)),
-                "volume_device_bytes": nbytes.value, "kernel": "vk::raymarch_staged_kernel" if lay.value == 6 else "vk::raymarch_naive_kernel"}
+                "volume_device_bytes": nbytes.value, "kernel": STAGED_KERNELS if lay.value == 6 else "vk::raymarch_naive_kernel"}
     finally:
         ctx.close()
 
@@ -881,7 +883,7 @@ def headline_line(R):
             achieved = alg / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("vk::raymarch_naive_kernel" if args.config == "c2" and args.layout in ("auto", "pairs", "packed") else "vk::raymarch_staged_kernel")
+                "kernel": ("vk::raymarch_naive_kernel" if args.config == "c2" and args.layout in ("auto", "pairs", "packed") else STAGED_KERNELS)
                           + " (one launch spanning %d frames: the active tiles are marched, strips at the end of the same grid write the clear"
                             " colour of the others)" % n_launch_frames,
                 "launch_ms": launch_ms, "frames_per_launch": n_launch_frames, "launches_timed": len(evs),
